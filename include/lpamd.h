@@ -1,0 +1,150 @@
+/*
+ * lpamd -- C ABI of the MI355X dense simplex-tableau engine.
+ *
+ * This is the drop-in seam for the reference's tableau path
+ * (`solver <file> simplex_tableau [max_cost|max_reduction]`).  The reference
+ * has no FFI of its own: LPModel holds raw `Tableau<real_t>*` / `List<real_t>*`
+ * pointers into a header-only template library (reference lp.h:273-279) and
+ * calls its methods from lp_simplex_tableau.cc.  Each entry point below names
+ * the reference interface whose work it takes over.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 on success and a negative
+ *    LPAMD_E_* code on failure, and never throws.  lpamd_last_error() gives the
+ *    message of the calling thread's last failure.
+ *  - solver outcomes travel through an `int* result` out-parameter using the
+ *    reference's `enum Result` values (reference lp.h:32-37), plus LPAMD_LIMIT.
+ *  - columns are addressed by GLOBAL column id: 0..N-1 = variables in
+ *    Variable::operator< order (reference base.cc:11-29, lp.cc:158-166),
+ *    N = right-hand-side column (`constant_index_`, reference lp.cc:167),
+ *    N+1 = phase-1 artificial column (reference lp_simplex_tableau.cc:70).
+ *  - host matrices are column-major fp64 with leading dimension `ld` >= m and
+ *    N+2 columns.  Host buffers are borrowed for the duration of the call;
+ *    outputs go into caller-allocated buffers.
+ *  - an engine is driven by one host thread at a time.  It owns its device
+ *    memory (HBM) until lpamd_destroy.
+ *  - multi-GPU: one engine per process/GPU holds the columns whose ordinal
+ *    (global id, with the RHS column skipped) is congruent to `rank` modulo
+ *    `world`, plus a replica of the RHS column.  The caller moves the two small
+ *    exchange buffers between ranks (all-gather of candidates, broadcast of the
+ *    pivot column); the library itself calls no collective.
+ */
+#ifndef LPAMD_H_
+#define LPAMD_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lpamd_engine lpamd_engine;
+
+/* reference lp.h:32-37 (enum Result) + one extra value for a pivot budget */
+enum { LPAMD_ERROR = 0, LPAMD_UNBOUNDED = 1, LPAMD_NOSOLUTION = 2, LPAMD_SOLVED = 3, LPAMD_LIMIT = 4 };
+/* reference lp.h:74-79 (enum LPModel::PivotingStrategy) */
+enum { LPAMD_PIVOTING_UNKNOWN = 0, LPAMD_SMALLEST_SUBSCRIPT = 1, LPAMD_MAX_COST = 2, LPAMD_MAX_REDUCTION = 3 };
+/* status codes */
+enum {
+  LPAMD_OK = 0,
+  LPAMD_E_ARG = -1,      /* bad argument / shape mismatch */
+  LPAMD_E_HIP = -2,      /* a HIP runtime call failed */
+  LPAMD_E_STATE = -3,    /* call not valid in the engine's current state */
+  LPAMD_E_NODEVICE = -4, /* no usable GPU */
+  LPAMD_E_UNSUPPORTED = -5
+};
+
+/* size in bytes of one candidate record / of the pivot-column exchange buffer */
+#define LPAMD_CANDIDATE_BYTES 32
+int64_t lpamd_exchange_bytes(int64_t m);
+
+const char* lpamd_last_error(void);
+/* version string of the library; also proves the symbol table loads without a GPU */
+const char* lpamd_version(void);
+
+/* ---- lifetime ----------------------------------------------------------
+ * Replaces `new Tableau<real_t>(rows, cols, format)`, `new List<real_t>()` and
+ * `new bool[...]` in LPModel::ToTableau (reference lp.cc:147-197): allocates
+ * the device-resident shard for an m-row tableau over N variables.
+ * `hip_stream` (a hipStream_t) may be NULL: the engine then creates its own. */
+int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t world, void* hip_stream);
+int lpamd_destroy(lpamd_engine* eng);
+
+/* ---- data in / out ------------------------------------------------------
+ * Replaces the row/objective appends of LPModel::ToTableau (reference
+ * lp.cc:171-196) and the `tableau_is_base_variable_` fill (lp.cc:156-166).
+ * T: m x (N+2) column-major, obj: N+2, is_basic: N+2 (entries N, N+1 ignored). */
+int lpamd_upload(lpamd_engine* eng, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic);
+/* Fills the shard on the device with the synthetic dense LP used by the
+ * benchmark (m rows, n structural + m slack columns, N must equal n + m);
+ * entry (i,j) depends only on (seed, i, j).  No reference counterpart. */
+int lpamd_fill_synthetic(lpamd_engine* eng, int64_t n_struct, uint64_t seed);
+/* Reads the shard back (what LPModel::PrintTableau iterates, reference
+ * lp.cc:199-219).  Columns owned by other ranks are left untouched. Any of
+ * T / obj / is_basic may be NULL. */
+int lpamd_download(const lpamd_engine* eng, double* T, int64_t ld, double* obj, uint8_t* is_basic);
+int lpamd_read_column(const lpamd_engine* eng, int64_t col, double* out_m);   /* Tableau::Col(j)  */
+int lpamd_read_row(const lpamd_engine* eng, int64_t row, double* out_Np2);    /* Tableau::Row(i), local columns only */
+int lpamd_write_objective(lpamd_engine* eng, const double* obj_Np2);          /* swaps opt_obj_tableau_, reference lp_simplex_tableau.cc:76-79,144 */
+int lpamd_basis_of_row(const lpamd_engine* eng, int64_t* out_m);              /* basic column of every row */
+
+/* ---- the hot-path steps, one call each (every call synchronises) ---------
+ * needTableauInitialization, reference lp_simplex_tableau.cc:54-62 */
+int lpamd_need_init(lpamd_engine* eng, int32_t* out);
+/* MAX_COST pricing loop, reference lp_simplex_tableau.cc:188-198; *e = -1 if none */
+int lpamd_price_max_cost(lpamd_engine* eng, int64_t* e);
+/* MAX_COST ratio test, reference lp_simplex_tableau.cc:207-227; *r = *d = -1 if unbounded */
+int lpamd_ratio_test(lpamd_engine* eng, int64_t e, int64_t* r, int64_t* d);
+/* MAX_REDUCTION pricing, reference lp_simplex_tableau.cc:235-364 */
+int lpamd_price_max_reduction(lpamd_engine* eng, int64_t* e, int64_t* r, int64_t* d);
+/* LPModel::TableauPivot(base, non_base, constraint_id), reference
+ * lp_simplex_tableau.cc:10-52 (d = column of `base`, e = column of `non_base`) */
+int lpamd_pivot(lpamd_engine* eng, int64_t d, int64_t e, int64_t r);
+/* LPModel::TableauSimplexInitialize, reference lp_simplex_tableau.cc:64-171 */
+int lpamd_phase1(lpamd_engine* eng, int32_t strategy, int32_t* result);
+/* LPModel::TableauSimplexSolve, reference lp_simplex_tableau.cc:173-379
+ * (phase 1 included).  max_pivots < 0: no budget. */
+int lpamd_solve(lpamd_engine* eng, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots);
+/* The `while (true)` body of TableauSimplexSolve (reference
+ * lp_simplex_tableau.cc:181-377) run device-resident for at most k pivots with
+ * no host round trip inside; *result = LPAMD_LIMIT if the budget ran out. */
+int lpamd_run_pivots(lpamd_engine* eng, int32_t strategy, int64_t k, int32_t* result, int64_t* done);
+/* GetTableauSimplexSolution's per-column values (reference
+ * lp_simplex_tableau.cc:381-399): x[j] for every global column (0 for
+ * non-basic, RHS and other ranks' columns); and the objective constant read by
+ * GetTableauSimplexOptimum (reference lp_simplex_tableau.cc:412-414). */
+int lpamd_column_values(lpamd_engine* eng, double* x_Np2);
+int lpamd_objective_constant(lpamd_engine* eng, double* out);
+
+/* (e, r) of every pivot applied since creation, in order. */
+int lpamd_pivot_count(const lpamd_engine* eng, int64_t* n);
+int lpamd_trace(const lpamd_engine* eng, int64_t* e, int64_t* r, int64_t cap, int64_t* n);
+
+/* HIP-event timing of the rank-1 update kernel (off by default). */
+int lpamd_set_profiling(lpamd_engine* eng, int32_t on);
+int lpamd_update_stats(lpamd_engine* eng, double* total_ms, int64_t* launches, int64_t* active_columns);
+
+/* ---- multi-GPU steps (column shards; the caller runs the collectives) ----
+ * These split one iteration of reference lp_simplex_tableau.cc:181-377 at the
+ * two points where column shards must talk.
+ * 1. every rank: best local entering candidate -> 32-byte record in device
+ *    memory `cand_dev` (asynchronous on the engine's stream). */
+int lpamd_local_candidate(lpamd_engine* eng, int32_t strategy, void* cand_dev);
+/* 2. caller all-gathers the records; every rank: pick the global winner with
+ *    the reference's lowest-index tie-break.  Synchronises (reads world*32 B).
+ *    *result = LPAMD_LIMIT while running, else the terminal Result. */
+int lpamd_select_candidate(lpamd_engine* eng, int32_t strategy, const void* cands_dev, int32_t world,
+                           int64_t* e, int64_t* r, int32_t* owner_rank, int32_t* result);
+/* 3. owner of column e: copy it into the exchange buffer (asynchronous). */
+int lpamd_export_column(lpamd_engine* eng, int64_t e, void* xbuf_dev);
+/* 4. caller broadcasts xbuf from the owner; every rank: ratio test on the
+ *    broadcast column (or the given row for MAX_REDUCTION), then the rank-1
+ *    update of its shard and RHS replica (asynchronous). */
+int lpamd_apply_pivot(lpamd_engine* eng, int32_t strategy, int64_t e, int64_t r, const void* xbuf_dev);
+/* terminal status after step 4 (synchronises): LPAMD_LIMIT = still running */
+int lpamd_poll(lpamd_engine* eng, int32_t* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LPAMD_H_ */

@@ -1,0 +1,10 @@
+"""MI355X-native dense simplex-tableau engine (host-side Python binding).
+
+The compute path is the HIP library `lib/liblpamd.so` (C ABI in
+include/lpamd.h).  There is no CPU fallback: importing `engine` without the
+built library, or creating an engine without a GPU, raises.
+"""
+from .engine import (  # noqa: F401
+    ERROR, UNBOUNDED, NOSOLUTION, SOLVED, LIMIT, MAX_COST, MAX_REDUCTION, STRATEGY,
+    LpamdError, TableauEngine, library, library_path,
+)

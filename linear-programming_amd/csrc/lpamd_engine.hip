@@ -1,0 +1,772 @@
+// Host side of the C ABI declared in include/lpamd.h: owns the device-resident
+// tableau shard, enqueues the kernels of lpamd_kernels.hip.h on one HIP stream
+// and keeps the pivot loop on the device (the host only reads the 64-byte
+// PivotState back once per batch of pivots).
+#include "lpamd_kernels.hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#include "lpamd.h"
+
+using namespace lpamd;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return set_err(LPAMD_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+#define LP_TRY(expr)            \
+  do {                          \
+    int _rc = (expr);           \
+    if (_rc != LPAMD_OK) return _rc; \
+  } while (0)
+
+// host copies of the reference's float-typed predicates (reference base.h:61-66)
+inline bool h_is_zero(double x) { return std::fabs((float)x) < 1e-6f; }
+inline bool h_is_neg(double x) { return (float)x <= -1e-6f; }
+inline bool h_is_nonneg(double x) { return (float)x > -1e-6f; }
+inline double h_flushz(double v) { return std::fabs(v) < (double)1e-6f ? 0.0 : v; }
+
+int status_to_result(int32_t st) { return st == ST_RUNNING ? LPAMD_LIMIT : st - 1; }
+
+}  // namespace
+
+struct lpamd_engine {
+  Shape sh{};
+  int32_t ncl = 0;          // nloc + 1
+  int32_t n_slabs = 0;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // device memory
+  double* T = nullptr;
+  double* obj = nullptr;
+  double* obj_saved = nullptr;
+  uint8_t* is_basic = nullptr;
+  int64_t* basis = nullptr;
+  double* colp = nullptr;
+  double* rowp = nullptr;   // also scratch for row gathers / column values
+  int32_t* active = nullptr;
+  double* cmin = nullptr;
+  int64_t* crow = nullptr;
+  Candidate* cand = nullptr;
+  PivotState* st = nullptr;
+  int64_t* trace = nullptr;
+  int64_t trace_cap = 0;
+  // host mirrors
+  PivotState h_st{};
+  bool loaded = false;
+  // profiling of the update kernel
+  bool profiling = false;
+  std::vector<hipEvent_t> ev;
+  size_t ev_used = 0;
+  double prof_ms = 0.0;
+  int64_t prof_launches = 0;
+  int64_t prof_active = 0;
+};
+
+namespace {
+
+int64_t round_up(int64_t x, int64_t q) { return (x + q - 1) / q * q; }
+
+bool owns(const lpamd_engine* e, int64_t gcol) {
+  if (gcol == e->sh.N) return true;  // RHS replica
+  return ordinal_of(gcol, e->sh.N) % e->sh.world == e->sh.rank;
+}
+int64_t local_of(const lpamd_engine* e, int64_t gcol) {
+  if (gcol == e->sh.N) return e->sh.nloc;
+  return ordinal_of(gcol, e->sh.N) / e->sh.world;
+}
+int64_t global_of(const lpamd_engine* e, int64_t l) {
+  if (l == e->sh.nloc) return e->sh.N;
+  return gcol_of(l * e->sh.world + e->sh.rank, e->sh.N);
+}
+
+int ensure_trace(lpamd_engine* e, int64_t need) {
+  if (need <= e->trace_cap) return LPAMD_OK;
+  int64_t cap = std::max<int64_t>(4096, e->trace_cap);
+  while (cap < need) cap *= 2;
+  int64_t* nt = nullptr;
+  HIP_TRY(hipMalloc(&nt, sizeof(int64_t) * 2 * cap));
+  if (e->trace) {
+    HIP_TRY(hipMemcpyAsync(nt, e->trace, sizeof(int64_t) * 2 * e->trace_cap, hipMemcpyDeviceToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipFree(e->trace));
+  }
+  e->trace = nt;
+  e->trace_cap = cap;
+  return LPAMD_OK;
+}
+
+int pull_state(lpamd_engine* e) {
+  HIP_TRY(hipMemcpyAsync(&e->h_st, e->st, sizeof(PivotState), hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return LPAMD_OK;
+}
+int push_state(lpamd_engine* e) {
+  HIP_TRY(hipMemcpyAsync(e->st, &e->h_st, sizeof(PivotState), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));   // h_st may be edited right after
+  return LPAMD_OK;
+}
+void reset_state(lpamd_engine* e) {
+  std::memset(&e->h_st, 0, sizeof(PivotState));
+  e->h_st.max_iter = std::numeric_limits<int64_t>::max();
+}
+
+int check_launch(const char* what) {
+  hipError_t err = hipGetLastError();
+  if (err != hipSuccess) return set_err(LPAMD_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(err));
+  return LPAMD_OK;
+}
+
+// --- enqueue helpers (no synchronisation) ---------------------------------
+int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
+  if (strategy == LPAMD_MAX_COST) {
+    hipLaunchKernelGGL(k_price_max_cost, dim3(1), dim3(kSelectThreads), 0, e->stream, e->obj, e->is_basic, e->sh, e->st, out);
+    return check_launch("k_price_max_cost");
+  }
+  if (strategy == LPAMD_MAX_REDUCTION) {
+    hipLaunchKernelGGL(k_pr_columns, dim3(e->sh.nloc), dim3(256), 0, e->stream, e->T, e->obj, e->is_basic, e->sh, e->st,
+                       e->cmin, e->crow);
+    LP_TRY(check_launch("k_pr_columns"));
+    hipLaunchKernelGGL(k_pr_select, dim3(1), dim3(kSelectThreads), 0, e->stream, e->obj, e->cmin, e->crow, e->sh, e->st, out);
+    return check_launch("k_pr_select");
+  }
+  // reference: neither branch of lp_simplex_tableau.cc:188/235 fires and the live
+  // assert at :14 aborts; here the call is rejected instead.
+  return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+}
+
+int enqueue_update(lpamd_engine* e) {
+  const int n_rc = (e->n_slabs + kUpdateSlabs - 1) / kUpdateSlabs;
+  const int cstride = std::max(1, 2048 / n_rc);
+  const int grid = cstride * n_rc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling) {
+    if (e->ev_used + 2 > e->ev.size()) {
+      for (int k = 0; k < 2; k++) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        e->ev.push_back(ev);
+      }
+    }
+    e0 = e->ev[e->ev_used++];
+    e1 = e->ev[e->ev_used++];
+    HIP_TRY(hipEventRecord(e0, e->stream));
+  }
+  hipLaunchKernelGGL(k_update, dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->n_slabs, e->colp, e->rowp,
+                     e->active, e->st);
+  LP_TRY(check_launch("k_update"));
+  if (e->profiling) HIP_TRY(hipEventRecord(e1, e->stream));
+  return LPAMD_OK;
+}
+
+// set-up + row gather + rank-1 update for the candidate in `cand`
+int enqueue_pivot(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override) {
+  if (find_row)
+    hipLaunchKernelGGL(k_pivot_setup<true>, dim3(1), dim3(kSelectThreads), 0, e->stream, e->T, e->sh, cand, xcol, e->basis,
+                       d_override, e->st, e->colp);
+  else
+    hipLaunchKernelGGL(k_pivot_setup<false>, dim3(1), dim3(kSelectThreads), 0, e->stream, e->T, e->sh, cand, xcol, e->basis,
+                       d_override, e->st, e->colp);
+  LP_TRY(check_launch("k_pivot_setup"));
+  hipLaunchKernelGGL(k_prep, dim3((e->ncl + 255) / 256), dim3(256), 0, e->stream, e->T, e->sh, e->obj, e->is_basic, e->basis,
+                     e->rowp, e->active, e->st, e->trace, e->trace_cap);
+  LP_TRY(check_launch("k_prep"));
+  return enqueue_update(e);
+}
+
+int enqueue_iteration(lpamd_engine* e, int strategy) {
+  LP_TRY(enqueue_pricing(e, strategy, e->cand));
+  return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, nullptr, -1);
+}
+
+// Device-resident main loop: at most `budget` pivots (budget < 0: none).
+int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
+  LP_TRY(pull_state(e));
+  e->h_st.status = ST_RUNNING;
+  e->h_st.max_iter = budget < 0 ? std::numeric_limits<int64_t>::max() : e->h_st.iter + budget;
+  LP_TRY(push_state(e));
+  // With a budget the whole run is enqueued at once (kernels turn into no-ops
+  // once the status leaves RUNNING); without one the batch grows geometrically.
+  int64_t batch = budget >= 0 ? 1024 : 8;
+  for (;;) {
+    int64_t todo = batch;
+    if (budget >= 0) todo = std::min<int64_t>(batch, e->h_st.max_iter - e->h_st.iter);
+    LP_TRY(ensure_trace(e, e->h_st.iter + todo));
+    for (int64_t k = 0; k < todo; k++) LP_TRY(enqueue_iteration(e, strategy));
+    LP_TRY(pull_state(e));
+    if (e->h_st.status != ST_RUNNING) break;
+    if (budget >= 0 && e->h_st.iter >= e->h_st.max_iter) { e->h_st.status = ST_LIMIT; break; }
+    batch = std::min<int64_t>(batch * 2, 1024);
+  }
+  *result = status_to_result(e->h_st.status);
+  return LPAMD_OK;
+}
+
+int read_local(const lpamd_engine* e, const void* src, void* dst, size_t bytes) {
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return LPAMD_OK;
+}
+
+int gather_row_host(const lpamd_engine* e, int64_t r, std::vector<double>& row_local) {
+  row_local.resize(e->ncl);
+  hipLaunchKernelGGL(k_gather_row, dim3((e->ncl + 255) / 256), dim3(256), 0, e->stream, e->T, e->sh.lda, e->ncl, r, e->rowp);
+  LP_TRY(check_launch("k_gather_row"));
+  return read_local(e, e->rowp, row_local.data(), sizeof(double) * e->ncl);
+}
+
+int single_gpu_only(const lpamd_engine* e, const char* what) {
+  if (e->sh.world != 1) return set_err(LPAMD_E_UNSUPPORTED, "%s needs the whole tableau on one GPU (world == 1)", what);
+  return LPAMD_OK;
+}
+
+#define CHECK_ENGINE(e)                                                        \
+  do {                                                                         \
+    if (!(e)) return set_err(LPAMD_E_ARG, "null engine");                      \
+    HIP_TRY(hipSetDevice((e)->device));                                        \
+  } while (0)
+#define CHECK_LOADED(e)                                                        \
+  do {                                                                         \
+    CHECK_ENGINE(e);                                                           \
+    if (!(e)->loaded) return set_err(LPAMD_E_STATE, "no tableau uploaded yet"); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+const char* lpamd_last_error(void) { return g_err; }
+const char* lpamd_version(void) { return "lpamd 0.1 (gfx950)"; }
+int64_t lpamd_exchange_bytes(int64_t m) { return round_up(std::max<int64_t>(m, 1), kSlabRows) * (int64_t)sizeof(double); }
+
+int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t world, void* hip_stream) {
+  if (!out) return set_err(LPAMD_E_ARG, "out is null");
+  *out = nullptr;
+  if (m <= 0 || N <= 0 || world <= 0 || rank < 0 || rank >= world)
+    return set_err(LPAMD_E_ARG, "bad shape m=%lld N=%lld rank=%d world=%d", (long long)m, (long long)N, rank, world);
+  const int64_t n_ord = N + 1;  // variables + artificial
+  const int64_t nloc = (n_ord - rank + world - 1) / world;
+  if (nloc <= 0) return set_err(LPAMD_E_ARG, "more ranks than columns");
+  if (nloc + 1 > (int64_t)std::numeric_limits<int32_t>::max() / 2) return set_err(LPAMD_E_ARG, "too many columns per rank");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
+  lpamd_engine* e = new lpamd_engine();
+  HIP_TRY(hipGetDevice(&e->device));
+  e->sh.m = m;
+  e->sh.N = N;
+  e->sh.lda = round_up(m, kSlabRows);
+  e->sh.nloc = (int32_t)nloc;
+  e->sh.rank = rank;
+  e->sh.world = world;
+  e->ncl = (int32_t)nloc + 1;
+  e->n_slabs = (int32_t)(e->sh.lda / kSlabRows);
+  if (hip_stream) {
+    e->stream = (hipStream_t)hip_stream;
+  } else {
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    e->own_stream = true;
+  }
+  const size_t tbytes = sizeof(double) * (size_t)e->sh.lda * (size_t)e->ncl;
+  hipError_t err = hipMalloc(&e->T, tbytes);
+  if (err != hipSuccess) {
+    delete e;
+    return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB for the tableau shard failed: %s", tbytes / 1e9, hipGetErrorString(err));
+  }
+  HIP_TRY(hipMalloc(&e->obj, sizeof(double) * e->ncl));
+  HIP_TRY(hipMalloc(&e->obj_saved, sizeof(double) * e->ncl));
+  HIP_TRY(hipMalloc(&e->is_basic, e->ncl));
+  HIP_TRY(hipMalloc(&e->basis, sizeof(int64_t) * m));
+  HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda));
+  HIP_TRY(hipMalloc(&e->rowp, sizeof(double) * std::max<int64_t>(e->ncl, e->sh.lda)));
+  HIP_TRY(hipMalloc(&e->active, sizeof(int32_t) * e->ncl));
+  HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
+  HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
+  HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
+  HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
+  HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda, e->stream));
+  HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));
+  std::memset(&e->h_st, 0, sizeof(PivotState));
+  LP_TRY(ensure_trace(e, 4096));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  *out = e;
+  return LPAMD_OK;
+}
+
+int lpamd_destroy(lpamd_engine* e) {
+  if (!e) return LPAMD_OK;
+  hipSetDevice(e->device);
+  hipStreamSynchronize(e->stream);
+  for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
+  void* ptrs[] = {e->T, e->obj, e->obj_saved, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->cand, e->st, e->trace};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  if (e->own_stream) hipStreamDestroy(e->stream);
+  delete e;
+  return LPAMD_OK;
+}
+
+int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic) {
+  CHECK_ENGINE(e);
+  const Shape& sh = e->sh;
+  if (!T || !obj || !is_basic || ld < sh.m) return set_err(LPAMD_E_ARG, "upload: null buffer or ld < m");
+  std::vector<double> hT((size_t)sh.lda * e->ncl, 0.0), hobj(e->ncl, 0.0);
+  std::vector<uint8_t> hb(e->ncl, 0);
+  for (int64_t l = 0; l < e->ncl; l++) {
+    const int64_t g = global_of(e, l);
+    std::memcpy(&hT[(size_t)l * sh.lda], T + g * ld, sizeof(double) * sh.m);
+    hobj[l] = obj[g];
+    hb[l] = (g == sh.N || g == sh.N + 1) ? 0 : (is_basic[g] ? 1 : 0);
+  }
+  // basic variable of every row: the discovery loop of reference
+  // lp_simplex_tableau.cc:240-251 (ascending basic columns, first non-zero row,
+  // later columns overwrite earlier ones), done once on the full host matrix.
+  std::vector<int64_t> basis(sh.m, -1);
+  for (int64_t g = 0; g < sh.N; g++) {
+    if (!is_basic[g]) continue;
+    for (int64_t i = 0; i < sh.m; i++)
+      if (!h_is_zero(T[g * ld + i])) { basis[i] = g; break; }
+  }
+  HIP_TRY(hipMemcpyAsync(e->T, hT.data(), sizeof(double) * hT.size(), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->obj, hobj.data(), sizeof(double) * e->ncl, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->is_basic, hb.data(), e->ncl, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(e->basis, basis.data(), sizeof(int64_t) * sh.m, hipMemcpyHostToDevice, e->stream));
+  reset_state(e);
+  LP_TRY(push_state(e));
+  e->loaded = true;
+  return LPAMD_OK;
+}
+
+int lpamd_fill_synthetic(lpamd_engine* e, int64_t n_struct, uint64_t seed) {
+  CHECK_ENGINE(e);
+  const Shape& sh = e->sh;
+  if (n_struct <= 0 || n_struct + sh.m != sh.N)
+    return set_err(LPAMD_E_ARG, "synthetic LP needs N == n_struct + m (N=%lld n=%lld m=%lld)", (long long)sh.N, (long long)n_struct, (long long)sh.m);
+  hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)((sh.lda + 255) / 256), (unsigned)e->ncl), dim3(256), 0, e->stream, e->T, e->obj,
+                     e->is_basic, e->basis, sh, n_struct, seed);
+  LP_TRY(check_launch("k_fill_synthetic"));
+  reset_state(e);
+  LP_TRY(push_state(e));
+  e->loaded = true;
+  return LPAMD_OK;
+}
+
+int lpamd_download(const lpamd_engine* e, double* T, int64_t ld, double* obj, uint8_t* is_basic) {
+  CHECK_LOADED(e);
+  const Shape& sh = e->sh;
+  if (T) {
+    if (ld < sh.m) return set_err(LPAMD_E_ARG, "download: ld < m");
+    std::vector<double> hT((size_t)sh.lda * e->ncl);
+    LP_TRY(read_local(e, e->T, hT.data(), sizeof(double) * hT.size()));
+    for (int64_t l = 0; l < e->ncl; l++)
+      std::memcpy(T + global_of(e, l) * ld, &hT[(size_t)l * sh.lda], sizeof(double) * sh.m);
+  }
+  if (obj) {
+    std::vector<double> h(e->ncl);
+    LP_TRY(read_local(e, e->obj, h.data(), sizeof(double) * e->ncl));
+    for (int64_t l = 0; l < e->ncl; l++) obj[global_of(e, l)] = h[l];
+  }
+  if (is_basic) {
+    std::vector<uint8_t> h(e->ncl);
+    LP_TRY(read_local(e, e->is_basic, h.data(), e->ncl));
+    for (int64_t l = 0; l < e->sh.nloc; l++) is_basic[global_of(e, l)] = h[l];
+  }
+  return LPAMD_OK;
+}
+
+int lpamd_read_column(const lpamd_engine* e, int64_t col, double* out) {
+  CHECK_LOADED(e);
+  if (col < 0 || col > e->sh.N + 1 || !out) return set_err(LPAMD_E_ARG, "read_column: bad column %lld", (long long)col);
+  if (!owns(e, col)) return set_err(LPAMD_E_ARG, "read_column: column %lld lives on another rank", (long long)col);
+  return read_local(e, e->T + local_of(e, col) * e->sh.lda, out, sizeof(double) * e->sh.m);
+}
+
+int lpamd_read_row(const lpamd_engine* e, int64_t row, double* out) {
+  CHECK_LOADED(e);
+  if (row < 0 || row >= e->sh.m || !out) return set_err(LPAMD_E_ARG, "read_row: bad row %lld", (long long)row);
+  std::vector<double> h;
+  LP_TRY(gather_row_host(e, row, h));
+  for (int64_t l = 0; l < e->ncl; l++) out[global_of(e, l)] = h[l];
+  return LPAMD_OK;
+}
+
+int lpamd_write_objective(lpamd_engine* e, const double* obj) {
+  CHECK_LOADED(e);
+  if (!obj) return set_err(LPAMD_E_ARG, "write_objective: null");
+  std::vector<double> h(e->ncl);
+  for (int64_t l = 0; l < e->ncl; l++) h[l] = obj[global_of(e, l)];
+  HIP_TRY(hipMemcpyAsync(e->obj, h.data(), sizeof(double) * e->ncl, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return LPAMD_OK;
+}
+
+int lpamd_basis_of_row(const lpamd_engine* e, int64_t* out) {
+  CHECK_LOADED(e);
+  if (!out) return set_err(LPAMD_E_ARG, "basis_of_row: null");
+  return read_local(e, e->basis, out, sizeof(int64_t) * e->sh.m);
+}
+
+int lpamd_need_init(lpamd_engine* e, int32_t* out) {
+  CHECK_LOADED(e);
+  if (!out) return set_err(LPAMD_E_ARG, "need_init: null");
+  std::vector<double> rhs(e->sh.m);
+  LP_TRY(read_local(e, e->T + (int64_t)e->sh.nloc * e->sh.lda, rhs.data(), sizeof(double) * e->sh.m));
+  *out = 0;
+  for (double b : rhs)
+    if (h_is_neg(b)) { *out = 1; break; }
+  return LPAMD_OK;
+}
+
+static int read_candidate(lpamd_engine* e, Candidate* c) { return read_local(e, e->cand, c, sizeof(Candidate)); }
+
+static int begin_step(lpamd_engine* e) {
+  LP_TRY(pull_state(e));
+  e->h_st.status = ST_RUNNING;
+  e->h_st.max_iter = std::numeric_limits<int64_t>::max();
+  return push_state(e);
+}
+
+int lpamd_price_max_cost(lpamd_engine* e, int64_t* col) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_price_max_cost"));
+  LP_TRY(begin_step(e));
+  LP_TRY(enqueue_pricing(e, LPAMD_MAX_COST, e->cand));
+  Candidate c;
+  LP_TRY(read_candidate(e, &c));
+  *col = c.gcol;
+  return LPAMD_OK;
+}
+
+int lpamd_price_max_reduction(lpamd_engine* e, int64_t* col, int64_t* r, int64_t* d) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_price_max_reduction"));
+  LP_TRY(begin_step(e));
+  LP_TRY(enqueue_pricing(e, LPAMD_MAX_REDUCTION, e->cand));
+  Candidate c;
+  LP_TRY(read_candidate(e, &c));
+  *col = c.gcol;
+  *r = c.row;
+  *d = -1;
+  if (c.row >= 0) LP_TRY(read_local(e, e->basis + c.row, d, sizeof(int64_t)));
+  return LPAMD_OK;
+}
+
+int lpamd_ratio_test(lpamd_engine* e, int64_t col, int64_t* r, int64_t* d) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_ratio_test"));
+  if (col < 0 || col > e->sh.N + 1 || col == e->sh.N) return set_err(LPAMD_E_ARG, "ratio_test: bad column %lld", (long long)col);
+  LP_TRY(begin_step(e));
+  Candidate c{0.0, col, -1, 0.0};
+  HIP_TRY(hipMemcpyAsync(e->cand, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
+  hipLaunchKernelGGL(k_pivot_setup<true>, dim3(1), dim3(kSelectThreads), 0, e->stream, e->T, e->sh, e->cand, (const double*)nullptr,
+                     e->basis, (int64_t)-1, e->st, e->colp);
+  LP_TRY(check_launch("k_pivot_setup"));
+  LP_TRY(pull_state(e));
+  if (e->h_st.status == ST_UNBOUNDED) { *r = -1; *d = -1; }
+  else { *r = e->h_st.r; *d = e->h_st.d; }
+  return LPAMD_OK;
+}
+
+int lpamd_pivot(lpamd_engine* e, int64_t d, int64_t col, int64_t r) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_pivot"));
+  const Shape& sh = e->sh;
+  if (col < 0 || col > sh.N + 1 || col == sh.N || r < 0 || r >= sh.m || d > sh.N + 1)
+    return set_err(LPAMD_E_ARG, "pivot: bad arguments d=%lld e=%lld r=%lld", (long long)d, (long long)col, (long long)r);
+  LP_TRY(begin_step(e));
+  LP_TRY(ensure_trace(e, e->h_st.iter + 1));
+  Candidate c{0.0, col, r, 0.0};
+  LP_TRY(read_local(e, e->obj + local_of(e, col), &c.ce, sizeof(double)));
+  HIP_TRY(hipMemcpyAsync(e->cand, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
+  LP_TRY(enqueue_pivot(e, false, e->cand, nullptr, d >= 0 ? d : (int64_t)(sh.N)));  // d<0: nothing to clear
+  return pull_state(e);
+}
+
+int lpamd_run_pivots(lpamd_engine* e, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_run_pivots"));
+  if (!result) return set_err(LPAMD_E_ARG, "run_pivots: null result");
+  LP_TRY(pull_state(e));
+  const int64_t it0 = e->h_st.iter;
+  LP_TRY(run_loop(e, strategy, k, result));
+  if (done) *done = e->h_st.iter - it0;
+  return LPAMD_OK;
+}
+
+// LPModel::TableauSimplexInitialize (reference lp_simplex_tableau.cc:64-171).
+// The pivots and the inner solve run on the device; the one-off scans around
+// them read single rows / columns back.
+int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_phase1"));
+  if (!result) return set_err(LPAMD_E_ARG, "phase1: null result");
+  const Shape& sh = e->sh;
+  const int64_t m = sh.m, N = sh.N, A = sh.N + 1, W = N + 2;
+  int32_t need = 0;
+  LP_TRY(lpamd_need_init(e, &need));
+  if (!need) { *result = LPAMD_SOLVED; return LPAMD_OK; }
+  *result = LPAMD_ERROR;
+  std::vector<double> saved(W, 0.0), tmp(W, 0.0), col(m), row(W, 0.0);
+  std::vector<uint8_t> basic(W, 0);
+  LP_TRY(lpamd_download(e, nullptr, 0, saved.data(), nullptr));
+  tmp[A] = -1.0;                                                       // :79
+  LP_TRY(lpamd_write_objective(e, tmp.data()));
+  const uint8_t zero8 = 0;
+  HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));   // :71
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T + local_of(e, A) * sh.lda, m, 1.0);  // :82-86
+  LP_TRY(check_launch("k_fill"));
+  LP_TRY(lpamd_read_column(e, N, col.data()));
+  int64_t r = -1;
+  double mv = 0.0;
+  for (int64_t i = 0; i < m; i++)                                      // MinReduce, ties to the later row (:88-91)
+    if (!(mv < col[i])) { mv = col[i]; r = i; }
+  if (r < 0) return LPAMD_OK;
+  LP_TRY(lpamd_read_row(e, r, row.data()));
+  LP_TRY(lpamd_download(e, nullptr, 0, nullptr, basic.data()));
+  int64_t d = -1;
+  for (int64_t j = 0; j < W; j++) {                                    // :94-104
+    if (j == N || h_is_zero(row[j])) continue;
+    if (basic[j]) { d = j; break; }
+  }
+  if (d < 0) return LPAMD_OK;
+  LP_TRY(lpamd_pivot(e, d, A, r));
+  LP_TRY(lpamd_read_column(e, N, col.data()));
+  for (int64_t i = 0; i < m; i++)                                      // :106-108 (live assert upstream)
+    if (!h_is_nonneg(col[i])) return LPAMD_OK;
+  int32_t inner = LPAMD_ERROR;
+  LP_TRY(run_loop(e, strategy, -1, &inner));                           // :110
+  if (inner != LPAMD_SOLVED) return LPAMD_OK;                          // :111 (live assert upstream)
+  double oc = 0.0;
+  LP_TRY(lpamd_objective_constant(e, &oc));
+  if (h_is_neg(oc)) { *result = LPAMD_NOSOLUTION; return LPAMD_OK; }   // :113-115
+  LP_TRY(lpamd_download(e, nullptr, 0, nullptr, basic.data()));
+  if (basic[A]) {                                                      // :117-135
+    LP_TRY(lpamd_read_column(e, A, col.data()));
+    bool pivoted = false;
+    for (int64_t i = 0; i < m && !pivoted; i++) {
+      if (h_is_zero(col[i])) continue;
+      LP_TRY(lpamd_read_row(e, i, row.data()));
+      for (int64_t j = 0; j < W; j++) {
+        if (j != N && basic[j]) continue;
+        if (h_is_zero(row[j])) continue;
+        if (j == N) return LPAMD_OK;  // upstream would pivot on the constant column and abort on its assert
+        LP_TRY(lpamd_pivot(e, A, j, i));
+        pivoted = true;
+        break;
+      }
+    }
+    if (!pivoted) return LPAMD_OK;
+    HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));
+    LP_TRY(lpamd_download(e, nullptr, 0, nullptr, basic.data()));
+  }
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T + local_of(e, A) * sh.lda, m, 0.0);  // :143
+  LP_TRY(check_launch("k_fill"));
+  saved[A] = 0.0;
+  // objective re-expression over the basic columns (:149-166)
+  std::vector<double> acc(W, 0.0);
+  for (int64_t j = 0; j < W; j++) {
+    if (j == N || !basic[j]) continue;
+    if (h_is_zero(saved[j])) continue;
+    LP_TRY(lpamd_read_column(e, j, col.data()));
+    int64_t rho = -1;
+    double bv = (double)1e-6f;                                         // MaxAbsReduce init {-1, kEpsilonF}
+    for (int64_t i = 0; i < m; i++)
+      if (!(std::fabs(bv) > std::fabs(col[i]))) { bv = col[i]; rho = i; }
+    if (rho < 0) return LPAMD_OK;
+    LP_TRY(lpamd_read_row(e, rho, row.data()));
+    const double s = -saved[j] / row[j];                               // :162
+    for (int64_t k = 0; k < W; k++) {
+      const double prod = row[k] * s;
+      acc[k] = h_flushz(acc[k] + prod);
+    }
+  }
+  for (int64_t k = 0; k < W; k++) saved[k] = h_flushz(saved[k] + acc[k]);  // :166
+  LP_TRY(lpamd_write_objective(e, saved.data()));
+  *result = LPAMD_SOLVED;
+  return LPAMD_OK;
+}
+
+int lpamd_solve(lpamd_engine* e, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots) {
+  CHECK_LOADED(e);
+  LP_TRY(single_gpu_only(e, "lpamd_solve"));
+  if (!result) return set_err(LPAMD_E_ARG, "solve: null result");
+  if (strategy != LPAMD_MAX_COST && strategy != LPAMD_MAX_REDUCTION)
+    return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+  int32_t need = 0;
+  LP_TRY(lpamd_need_init(e, &need));
+  if (need) {                                                          // reference lp_simplex_tableau.cc:174-178
+    int32_t r1 = LPAMD_ERROR;
+    LP_TRY(lpamd_phase1(e, strategy, &r1));
+    if (r1 != LPAMD_SOLVED) {
+      *result = r1 == LPAMD_NOSOLUTION ? LPAMD_NOSOLUTION : LPAMD_ERROR;
+      if (n_pivots) *n_pivots = e->h_st.iter;
+      return LPAMD_OK;
+    }
+    LP_TRY(lpamd_need_init(e, &need));
+    if (need) { *result = LPAMD_ERROR; return LPAMD_OK; }              // :179
+  }
+  LP_TRY(run_loop(e, strategy, max_pivots, result));
+  if (n_pivots) *n_pivots = e->h_st.iter;
+  return LPAMD_OK;
+}
+
+int lpamd_column_values(lpamd_engine* e, double* x) {
+  CHECK_LOADED(e);
+  if (!x) return set_err(LPAMD_E_ARG, "column_values: null");
+  hipLaunchKernelGGL(k_column_values, dim3(e->sh.nloc), dim3(256), 0, e->stream, e->T, e->is_basic, e->sh, e->rowp);
+  LP_TRY(check_launch("k_column_values"));
+  std::vector<double> h(e->sh.nloc);
+  LP_TRY(read_local(e, e->rowp, h.data(), sizeof(double) * e->sh.nloc));
+  for (int64_t j = 0; j < e->sh.N + 2; j++) x[j] = 0.0;
+  for (int64_t l = 0; l < e->sh.nloc; l++) x[global_of(e, l)] = h[l];
+  return LPAMD_OK;
+}
+
+int lpamd_objective_constant(lpamd_engine* e, double* out) {
+  CHECK_LOADED(e);
+  if (!out) return set_err(LPAMD_E_ARG, "objective_constant: null");
+  return read_local(e, e->obj + e->sh.nloc, out, sizeof(double));
+}
+
+int lpamd_pivot_count(const lpamd_engine* e, int64_t* n) {
+  CHECK_LOADED(e);
+  LP_TRY(pull_state(const_cast<lpamd_engine*>(e)));
+  *n = e->h_st.iter;
+  return LPAMD_OK;
+}
+
+int lpamd_trace(const lpamd_engine* e, int64_t* te, int64_t* tr, int64_t cap, int64_t* n) {
+  CHECK_LOADED(e);
+  LP_TRY(pull_state(const_cast<lpamd_engine*>(e)));
+  const int64_t k = std::min<int64_t>(std::min<int64_t>(e->h_st.iter, e->trace_cap), cap);
+  std::vector<int64_t> h(2 * std::max<int64_t>(k, 1));
+  if (k > 0) LP_TRY(read_local(e, e->trace, h.data(), sizeof(int64_t) * 2 * k));
+  for (int64_t i = 0; i < k; i++) { te[i] = h[2 * i]; tr[i] = h[2 * i + 1]; }
+  if (n) *n = e->h_st.iter;
+  return LPAMD_OK;
+}
+
+int lpamd_set_profiling(lpamd_engine* e, int32_t on) {
+  CHECK_ENGINE(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  e->profiling = on != 0;
+  e->ev_used = 0;
+  e->prof_ms = 0.0;
+  e->prof_launches = 0;
+  e->prof_active = 0;
+  return LPAMD_OK;
+}
+
+int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int64_t* active_columns) {
+  CHECK_ENGINE(e);
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  for (size_t k = 0; k + 1 < e->ev_used; k += 2) {
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e->ev[k], e->ev[k + 1]));
+    e->prof_ms += ms;
+    e->prof_launches++;
+  }
+  e->ev_used = 0;
+  LP_TRY(pull_state(e));
+  e->prof_active = e->h_st.n_active;
+  if (total_ms) *total_ms = e->prof_ms;
+  if (launches) *launches = e->prof_launches;
+  if (active_columns) *active_columns = e->prof_active;
+  return LPAMD_OK;
+}
+
+// ------------------------------------------------------------- multi-GPU steps
+int lpamd_local_candidate(lpamd_engine* e, int32_t strategy, void* cand_dev) {
+  CHECK_LOADED(e);
+  if (!cand_dev) return set_err(LPAMD_E_ARG, "local_candidate: null buffer");
+  return enqueue_pricing(e, strategy, (Candidate*)cand_dev);
+}
+
+int lpamd_select_candidate(lpamd_engine* e, int32_t strategy, const void* cands_dev, int32_t world, int64_t* col, int64_t* r,
+                           int32_t* owner_rank, int32_t* result) {
+  CHECK_LOADED(e);
+  if (!cands_dev || world != e->sh.world || !col || !r || !owner_rank || !result)
+    return set_err(LPAMD_E_ARG, "select_candidate: bad arguments");
+  std::vector<Candidate> c(world);
+  LP_TRY(read_local(e, cands_dev, c.data(), sizeof(Candidate) * world));
+  LP_TRY(pull_state(e));
+  *col = -1;
+  *r = -1;
+  *owner_rank = -1;
+  if (e->h_st.status != ST_RUNNING) { *result = status_to_result(e->h_st.status); return LPAMD_OK; }
+  Candidate best{-DBL_MAX, -1, -1, 0.0};
+  bool any = false;
+  for (const Candidate& k : c) {
+    if (k.gcol < 0) continue;
+    any = true;
+    if (strategy == LPAMD_MAX_REDUCTION && k.row < 0) continue;
+    if (best.gcol < 0 || k.key > best.key || (k.key == best.key && k.gcol < best.gcol)) best = k;
+  }
+  if (best.gcol < 0) {
+    *result = any ? LPAMD_UNBOUNDED : LPAMD_SOLVED;   // reference lp_simplex_tableau.cc:365-373 / 201-205
+    return LPAMD_OK;
+  }
+  HIP_TRY(hipMemcpyAsync(e->cand, &best, sizeof(Candidate), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));   // `best` is a stack object
+  *col = best.gcol;
+  *r = best.row;
+  *owner_rank = (int32_t)(ordinal_of(best.gcol, e->sh.N) % e->sh.world);
+  *result = LPAMD_LIMIT;
+  return LPAMD_OK;
+}
+
+int lpamd_export_column(lpamd_engine* e, int64_t col, void* xbuf_dev) {
+  CHECK_LOADED(e);
+  if (!xbuf_dev || col < 0 || col > e->sh.N + 1 || col == e->sh.N) return set_err(LPAMD_E_ARG, "export_column: bad arguments");
+  if (!owns(e, col)) return set_err(LPAMD_E_ARG, "export_column: column %lld lives on another rank", (long long)col);
+  HIP_TRY(hipMemcpyAsync(xbuf_dev, e->T + local_of(e, col) * e->sh.lda, sizeof(double) * e->sh.lda, hipMemcpyDeviceToDevice, e->stream));
+  return LPAMD_OK;
+}
+
+int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r, const void* xbuf_dev) {
+  CHECK_LOADED(e);
+  (void)col;
+  (void)r;
+  if (!xbuf_dev) return set_err(LPAMD_E_ARG, "apply_pivot: null exchange buffer");
+  LP_TRY(ensure_trace(e, e->h_st.iter + 2));   // h_st was refreshed by lpamd_select_candidate
+  return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, (const double*)xbuf_dev, -1);
+}
+
+// Debug aid: scalars of the last pivot set-up {e, r, d, a, ce, f, g, n_active}.
+int lpamd_debug_state(lpamd_engine* e, double* out8) {
+  CHECK_LOADED(e);
+  LP_TRY(pull_state(e));
+  out8[0] = (double)e->h_st.e; out8[1] = (double)e->h_st.r; out8[2] = (double)e->h_st.d; out8[3] = e->h_st.a;
+  out8[4] = e->h_st.ce; out8[5] = e->h_st.f; out8[6] = e->h_st.g; out8[7] = (double)e->h_st.n_active;
+  return LPAMD_OK;
+}
+
+int lpamd_poll(lpamd_engine* e, int32_t* result) {
+  CHECK_LOADED(e);
+  LP_TRY(pull_state(e));
+  *result = status_to_result(e->h_st.status);
+  return LPAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,429 @@
+// Device kernels of the dense simplex-tableau engine (gfx950 / CDNA4, wave64).
+//
+// All arithmetic that reaches the tableau is written with __dmul_rn/__dadd_rn
+// so that no multiply-add is contracted into an FMA: the reference build has
+// no FMA (x86-64 baseline) and its pivot sequence depends on every product and
+// sum being rounded separately.  The file is also compiled with
+// -ffp-contract=off.
+//
+// Data layout (per engine / GPU):
+//   T        column-major fp64, leading dimension lda (multiple of 512 rows,
+//            padding rows are zero and stay zero), ncl = nloc + 1 columns:
+//            local column l < nloc holds the variable column whose ordinal is
+//            l * world + rank; local column nloc is the replica of the
+//            right-hand-side column.
+//   obj      ncl doubles, the objective row laid out like the columns.
+//   is_basic ncl bytes.
+//   basis    m int64: global column id of the basic variable of every row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+namespace lpamd {
+
+constexpr int kSlabRows = 512;        // rows covered by one 256-thread block with 16 B per lane
+constexpr int kUpdateThreads = 256;
+constexpr int kUpdateSlabs = 4;       // slabs (of 512 rows) a block keeps in registers
+constexpr int kSelectThreads = 1024;  // single-workgroup selection kernels
+constexpr int kWave = 64;
+
+// device-side status: 0 while running, otherwise (reference Result value + 1)
+enum : int32_t { ST_RUNNING = 0, ST_ERROR = 1, ST_UNBOUNDED = 2, ST_NOSOLUTION = 3, ST_SOLVED = 4, ST_LIMIT = 5 };
+
+struct Candidate {   // 32 bytes, also the multi-GPU exchange record
+  double key;        // MAX_COST: reduced cost c_e.  MAX_REDUCTION: c_e * min ratio
+  int64_t gcol;      // global column id, -1 = no candidate
+  int64_t row;       // MAX_REDUCTION: pivot row (or -1 = column has no eligible row)
+  double ce;         // objective coefficient of gcol
+};
+
+struct PivotState {  // device resident, one per engine
+  int32_t status;
+  int32_t pad0;
+  int64_t iter;      // pivots applied so far (index into the trace)
+  int64_t max_iter;  // pricing reports ST_LIMIT once iter reaches this
+  int64_t e, r, d;   // global ids of entering / leaving column and the pivot row
+  double a, ce, f, g;
+  int32_t n_active;  // local columns whose pivot-row entry is non-zero
+  int32_t pad1;
+};
+
+struct Shape {
+  int64_t m, lda, N;
+  int32_t nloc;      // owned variable columns (RHS replica is local column nloc)
+  int32_t rank, world;
+};
+
+// reference base.h:61-66: the predicates take float, so the double is narrowed first.
+__device__ __forceinline__ bool is_pos(double x) { return (float)x >= 1e-6f; }
+__device__ __forceinline__ bool is_neg(double x) { return (float)x <= -1e-6f; }
+__device__ __forceinline__ bool is_zero(double x) { return fabsf((float)x) < 1e-6f; }
+// reference lp_simplex_tableau.cc:5-8: entries below 1e-6f (as a double) are dropped after every add.
+__device__ __forceinline__ double flushz(double v) { return fabs(v) < (double)1e-6f ? 0.0 : v; }
+
+__host__ __device__ __forceinline__ int64_t ordinal_of(int64_t gcol, int64_t N) { return gcol < N ? gcol : N; }
+__host__ __device__ __forceinline__ int64_t gcol_of(int64_t ord, int64_t N) { return ord < N ? ord : N + 1; }
+
+// ---------------------------------------------------------------- reductions
+// "larger key wins, lower index breaks ties"; index -1 = empty.
+__device__ __forceinline__ void take_max(double& bv, int64_t& bi, double v, int64_t i) {
+  if (i >= 0 && (bi < 0 || v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+}
+__device__ __forceinline__ void take_min(double& bv, int64_t& bi, double v, int64_t i) {
+  if (i >= 0 && (bi < 0 || v < bv || (v == bv && i < bi))) { bv = v; bi = i; }
+}
+
+template <bool kMax>
+__device__ __forceinline__ void wave_arg(double& v, int64_t& i) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) {
+    const double ov = __shfl_down(v, off, kWave);
+    const int64_t oi = __shfl_down(i, off, kWave);
+    if (kMax) take_max(v, i, ov, oi); else take_min(v, i, ov, oi);
+  }
+}
+
+// Wavefront-level arg-reduce followed by an LDS stage across the block's waves.
+// Result valid in thread 0.
+template <bool kMax, int kThreads>
+__device__ __forceinline__ void block_arg(double& v, int64_t& i, double* s_v, int64_t* s_i) {
+  constexpr int kWaves = kThreads / kWave;
+  wave_arg<kMax>(v, i);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) { s_v[wave] = v; s_i[wave] = i; }
+  __syncthreads();
+  if (wave == 0) {
+    v = lane < kWaves ? s_v[lane] : 0.0;
+    i = lane < kWaves ? s_i[lane] : -1;
+    wave_arg<kMax>(v, i);
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ pricing
+// MAX_COST pricing (reference lp_simplex_tableau.cc:188-198): largest positive
+// reduced cost over non-basic columns, lowest column index on ties.
+__global__ __launch_bounds__(kSelectThreads) void k_price_max_cost(
+    const double* __restrict__ obj, const uint8_t* __restrict__ is_basic, Shape sh,
+    const PivotState* __restrict__ st, Candidate* __restrict__ cand) {
+  __shared__ double s_v[kSelectThreads / kWave];
+  __shared__ int64_t s_i[kSelectThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  double bv = -DBL_MAX;
+  int64_t bi = -1;
+  for (int l = threadIdx.x; l < sh.nloc; l += kSelectThreads) {
+    if (is_basic[l]) continue;
+    const double c = obj[l];
+    if (is_pos(c) && c > bv) { bv = c; bi = l; }
+  }
+  block_arg<true, kSelectThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    Candidate c;
+    c.key = bv;
+    c.ce = bv;
+    c.row = -1;
+    c.gcol = bi < 0 ? -1 : gcol_of(bi * sh.world + sh.rank, sh.N);
+    *cand = c;
+  }
+}
+
+// MAX_REDUCTION pricing, per-column part (reference lp_simplex_tableau.cc:291-302
+// and 341-352): one workgroup per candidate column computes the minimum ratio
+// b_i / (-T_ij) over rows with (float)T_ij <= -1e-6f, lowest row on ties.
+// crow[l] = -2: not a candidate, -1: candidate without eligible row.
+__global__ __launch_bounds__(256) void k_pr_columns(
+    const double* __restrict__ T, const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
+    Shape sh, const PivotState* __restrict__ st, double* __restrict__ cmin, int64_t* __restrict__ crow) {
+  __shared__ double s_v[256 / kWave];
+  __shared__ int64_t s_i[256 / kWave];
+  if (st->status != ST_RUNNING) return;
+  const int l = blockIdx.x;
+  if (is_basic[l] || !is_pos(obj[l])) {
+    if (threadIdx.x == 0) crow[l] = -2;
+    return;
+  }
+  const double* __restrict__ col = T + (int64_t)l * sh.lda;
+  const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < sh.m; i += 256) {
+    const double a = col[i];
+    if ((float)a > -1e-6f) continue;          // _IsNonNegative
+    const double ratio = rhs[i] / (-a);
+    if (bv > ratio) { bv = ratio; bi = i; }
+  }
+  block_arg<false, 256>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) { cmin[l] = bv; crow[l] = bi; }
+}
+
+// MAX_REDUCTION pricing, fold over columns (reference lp_simplex_tableau.cc:310-325
+// and 353-362): largest c_j * min_j over candidates that have a row, lowest
+// column on ties; if no candidate has a row the first candidate is reported
+// with row = -1 (=> unbounded).
+__global__ __launch_bounds__(kSelectThreads) void k_pr_select(
+    const double* __restrict__ obj, const double* __restrict__ cmin, const int64_t* __restrict__ crow,
+    Shape sh, const PivotState* __restrict__ st, Candidate* __restrict__ cand) {
+  __shared__ double s_v[kSelectThreads / kWave];
+  __shared__ int64_t s_i[kSelectThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  double bv = -DBL_MAX, fv = 0.0;
+  int64_t bi = -1, fi = -1;
+  for (int l = threadIdx.x; l < sh.nloc; l += kSelectThreads) {
+    const int64_t cr = crow[l];
+    if (cr == -2) continue;
+    if (fi < 0) fi = l;
+    if (cr < 0) continue;
+    const double score = __dmul_rn(obj[l], cmin[l]);
+    if (score > bv) { bv = score; bi = l; }
+  }
+  block_arg<true, kSelectThreads>(bv, bi, s_v, s_i);
+  // first candidate = smallest local index: reduce with key = -index
+  fv = fi < 0 ? 0.0 : -(double)fi;
+  block_arg<true, kSelectThreads>(fv, fi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    Candidate c;
+    if (bi >= 0) {
+      c.key = bv; c.gcol = gcol_of(bi * sh.world + sh.rank, sh.N); c.row = crow[bi]; c.ce = obj[bi];
+    } else if (fi >= 0) {
+      c.key = -DBL_MAX; c.gcol = gcol_of(fi * sh.world + sh.rank, sh.N); c.row = -1; c.ce = obj[fi];
+    } else {
+      c.key = -DBL_MAX; c.gcol = -1; c.row = -1; c.ce = 0.0;
+    }
+    *cand = c;
+  }
+}
+
+// ------------------------------------------------------- ratio test + set-up
+// One workgroup.  kFindRow: the MAX_COST ratio test (reference
+// lp_simplex_tableau.cc:207-227) as an LDS-staged arg-min over the pivot
+// column (taken from the local shard, or from `xcol` when the column was
+// broadcast by its owner); otherwise the row comes with the candidate.
+// Then fixes the scalars of TableauPivot (reference lp_simplex_tableau.cc:33-44)
+// and writes col' (pivot column with col'[r] = 1 + a) into colp.
+template <bool kFindRow>
+__global__ __launch_bounds__(kSelectThreads) void k_pivot_setup(
+    const double* __restrict__ T, Shape sh, const Candidate* __restrict__ cand,
+    const double* __restrict__ xcol, const int64_t* __restrict__ basis, int64_t d_override,
+    PivotState* __restrict__ st, double* __restrict__ colp) {
+  __shared__ double s_v[kSelectThreads / kWave];
+  __shared__ int64_t s_i[kSelectThreads / kWave];
+  __shared__ int64_t s_r;
+  if (st->status != ST_RUNNING) return;
+  const Candidate c = *cand;
+  if (st->iter >= st->max_iter) { if (threadIdx.x == 0) st->status = ST_LIMIT; return; }
+  if (c.gcol < 0) { if (threadIdx.x == 0) st->status = ST_SOLVED; return; }
+  const int64_t eo = ordinal_of(c.gcol, sh.N);
+  const double* __restrict__ col = xcol ? xcol : T + (eo / sh.world) * sh.lda;
+  const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+  int64_t r;
+  if (kFindRow) {
+    double bv = DBL_MAX;
+    int64_t bi = -1;
+    for (int64_t i = threadIdx.x; i < sh.m; i += kSelectThreads) {
+      const double a = col[i];
+      if ((float)a > -1e-6f) continue;   // skips _IsZero and _IsNonNegative entries alike
+      const double ratio = rhs[i] / (-a);
+      if (bv > ratio) { bv = ratio; bi = i; }
+    }
+    block_arg<false, kSelectThreads>(bv, bi, s_v, s_i);
+    if (threadIdx.x == 0) s_r = bi;
+    __syncthreads();
+    r = s_r;
+  } else {
+    r = c.row;
+  }
+  if (r < 0) { if (threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
+  const double a = col[r];
+  if (threadIdx.x == 0) {
+    const double f = -1.0 / a;                       // lp_simplex_tableau.cc:40
+    st->e = c.gcol;
+    st->r = r;
+    st->d = d_override >= 0 ? d_override : basis[r];
+    st->a = a;
+    st->ce = c.ce;
+    st->f = f;
+    st->g = __dmul_rn(c.ce, f);                      // lp_simplex_tableau.cc:34-35
+    st->n_active = 0;
+  }
+  for (int64_t i = threadIdx.x; i < sh.m; i += kSelectThreads)
+    colp[i] = (i == r) ? __dadd_rn(1.0, a) : col[i]; // lp_simplex_tableau.cc:41-44
+}
+
+// ------------------------------------------------------------ row gather
+// One thread per local column (RHS replica included): row' = T[r][.] * f, the
+// objective-row update obj += T[r][.] * g (reference lp_simplex_tableau.cc:33-40),
+// and the list of columns the rank-1 update has to touch (row' != 0).  Thread 0
+// also does the bookkeeping of reference lp_simplex_tableau.cc:16-28.
+__global__ __launch_bounds__(256) void k_prep(
+    const double* __restrict__ T, Shape sh, double* __restrict__ obj, uint8_t* __restrict__ is_basic,
+    int64_t* __restrict__ basis, double* __restrict__ rowp, int32_t* __restrict__ active,
+    PivotState* __restrict__ st, int64_t* __restrict__ trace, int64_t trace_cap) {
+  if (st->status != ST_RUNNING) return;
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ncl = sh.nloc + 1;
+  const int64_t e = st->e, r = st->r, d = st->d;
+  const double f = st->f, g = st->g;
+  bool act = false;
+  if (l < ncl) {
+    const double t = T[(int64_t)l * sh.lda + r];
+    const double rp = __dmul_rn(t, f);
+    double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g)));
+    const int64_t eo = ordinal_of(e, sh.N);
+    if (l < sh.nloc && eo % sh.world == sh.rank && eo / sh.world == l) o = 0.0;   // :37
+    obj[l] = o;
+    rowp[l] = rp;
+    act = rp != 0.0;
+  }
+  // wave-aggregated append to the active list
+  const unsigned long long mask = __ballot(act);
+  if (mask) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int leader = __ffsll((long long)mask) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&st->n_active, __popcll(mask));
+    base = __shfl(base, leader, kWave);
+    if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+  }
+  if (l == 0) {
+    const int64_t eo = ordinal_of(e, sh.N);
+    if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+    if (d >= 0 && d != sh.N) {
+      const int64_t dord = ordinal_of(d, sh.N);
+      if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+    }
+    basis[r] = e;
+    const int64_t it = st->iter;
+    if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = r; }
+    st->iter = it + 1;
+  }
+}
+
+// ------------------------------------------------------------ rank-1 update
+// T[:, j] = flush(T[:, j] + col' * row'[j]) for every active column j
+// (reference lp_simplex_tableau.cc:45-46).  HBM-bound: every entry of an
+// active column is read once and written once (16 B/entry), 16 B per lane
+// per access.  A block owns a chunk of kUpdateSlabs*512 rows, keeps that
+// chunk of col' in registers and walks over its share of the active columns,
+// two columns per step so that 128 B per lane are in flight.
+__global__ __launch_bounds__(kUpdateThreads) void k_update(
+    double* __restrict__ T, int64_t lda, int32_t n_slabs, const double* __restrict__ colp,
+    const double* __restrict__ rowp, const int32_t* __restrict__ active,
+    const PivotState* __restrict__ st) {
+  if (st->status != ST_RUNNING) return;
+  const int n_rc = (n_slabs + kUpdateSlabs - 1) / kUpdateSlabs;
+  const int rc = blockIdx.x % n_rc;
+  const int cstart = blockIdx.x / n_rc, cstride = gridDim.x / n_rc;
+  const int n_active = st->n_active;
+  const int64_t row0 = (int64_t)rc * kUpdateSlabs * kSlabRows + threadIdx.x * 2;
+  const int my_slabs = min(kUpdateSlabs, n_slabs - rc * kUpdateSlabs);
+  double2 c[kUpdateSlabs];
+#pragma unroll
+  for (int s = 0; s < kUpdateSlabs; s++)
+    c[s] = s < my_slabs ? *reinterpret_cast<const double2*>(colp + row0 + s * kSlabRows) : make_double2(0.0, 0.0);
+
+  auto apply = [&](double2 t, double2 cc, double rj) {
+    double2 o;
+    o.x = flushz(__dadd_rn(t.x, __dmul_rn(cc.x, rj)));
+    o.y = flushz(__dadd_rn(t.y, __dmul_rn(cc.y, rj)));
+    return o;
+  };
+
+  int k = cstart;
+  if (my_slabs == kUpdateSlabs) {
+    for (; k + cstride < n_active; k += 2 * cstride) {
+      const int l0 = active[k], l1 = active[k + cstride];
+      const double r0 = rowp[l0], r1 = rowp[l1];
+      double2* p0 = reinterpret_cast<double2*>(T + (int64_t)l0 * lda + row0);
+      double2* p1 = reinterpret_cast<double2*>(T + (int64_t)l1 * lda + row0);
+      double2 t0[kUpdateSlabs], t1[kUpdateSlabs];
+#pragma unroll
+      for (int s = 0; s < kUpdateSlabs; s++) t0[s] = p0[s * (kSlabRows / 2)];
+#pragma unroll
+      for (int s = 0; s < kUpdateSlabs; s++) t1[s] = p1[s * (kSlabRows / 2)];
+#pragma unroll
+      for (int s = 0; s < kUpdateSlabs; s++) p0[s * (kSlabRows / 2)] = apply(t0[s], c[s], r0);
+#pragma unroll
+      for (int s = 0; s < kUpdateSlabs; s++) p1[s * (kSlabRows / 2)] = apply(t1[s], c[s], r1);
+    }
+  }
+  for (; k < n_active; k += cstride) {
+    const int l0 = active[k];
+    const double r0 = rowp[l0];
+    double2* p0 = reinterpret_cast<double2*>(T + (int64_t)l0 * lda + row0);
+#pragma unroll
+    for (int s = 0; s < kUpdateSlabs; s++)
+      if (s < my_slabs) p0[s * (kSlabRows / 2)] = apply(p0[s * (kSlabRows / 2)], c[s], r0);
+  }
+}
+
+// --------------------------------------------------------------- utilities
+__global__ void k_gather_row(const double* __restrict__ T, int64_t lda, int32_t ncl, int64_t r, double* __restrict__ out) {
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l < ncl) out[l] = T[(int64_t)l * lda + r];
+}
+
+__global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// GetTableauSimplexSolution, per-column part (reference lp_simplex_tableau.cc:388-399):
+// for a basic column the LAST row with a non-zero entry defines x = -b_i / T_ij.
+__global__ __launch_bounds__(256) void k_column_values(
+    const double* __restrict__ T, const uint8_t* __restrict__ is_basic, Shape sh, double* __restrict__ x) {
+  __shared__ double s_v[256 / kWave];
+  __shared__ int64_t s_i[256 / kWave];
+  const int l = blockIdx.x;
+  if (!is_basic[l]) { if (threadIdx.x == 0) x[l] = 0.0; return; }
+  const double* __restrict__ col = T + (int64_t)l * sh.lda;
+  double bv = 0.0;
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < sh.m; i += 256)
+    if (!is_zero(col[i])) { bv = (double)i; bi = i; }
+  block_arg<true, 256>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    const double* rhs = T + (int64_t)sh.nloc * sh.lda;
+    x[l] = bi < 0 ? 0.0 : -rhs[bi] / col[bi];
+  }
+}
+
+// ---- synthetic dense LP: entry (i, j) is a pure function of (seed, i, j) ----
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__host__ __device__ __forceinline__ double u01(uint64_t seed, uint64_t i, uint64_t j) {
+  const uint64_t h = splitmix64(splitmix64(seed ^ (i * 0xD1B54A32D192ED03ull)) ^ (j * 0x8CB92BA72F3D8DD7ull));
+  return (double)(h >> 11) * 0x1.0p-53;
+}
+// max c.x  s.t.  A x <= b, x >= 0 in the reference's slack-form convention
+// (row i reads 0 = b_i + sum_j T_ij x_j, reference lp.cc:135-145): structural
+// column j < n: -A_ij, A ~ U(0.1, 1.1); slack column n+i: -1; RHS: b_i ~ U(1,2)*n;
+// objective c_j ~ U(0.5, 1.5).  Row index m addresses the objective row.
+__host__ __device__ __forceinline__ double synth_entry(uint64_t seed, int64_t m, int64_t n, int64_t i, int64_t j) {
+  const int64_t N = n + m;
+  if (i == m) return j < n ? 0.5 + u01(seed, (uint64_t)m, (uint64_t)j) : 0.0;
+  if (j < n) return -(0.1 + u01(seed, (uint64_t)i, (uint64_t)j));
+  if (j < N) return (j - n == i) ? -1.0 : 0.0;
+  if (j == N) return (1.0 + u01(seed, (uint64_t)i, (uint64_t)N)) * (double)n;
+  return 0.0;
+}
+
+__global__ __launch_bounds__(256) void k_fill_synthetic(
+    double* __restrict__ T, double* __restrict__ obj, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
+    Shape sh, int64_t n, uint64_t seed) {
+  const int l = blockIdx.y;                       // local column, nloc = RHS replica
+  const int64_t g = l < sh.nloc ? gcol_of((int64_t)l * sh.world + sh.rank, sh.N) : sh.N;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sh.lda) T[(int64_t)l * sh.lda + i] = i < sh.m ? synth_entry(seed, sh.m, n, i, g) : 0.0;
+  if (i == 0) {
+    obj[l] = synth_entry(seed, sh.m, n, sh.m, g);
+    is_basic[l] = (l < sh.nloc && g >= n && g < n + sh.m) ? 1 : 0;
+  }
+  if (l == 0 && i < sh.m) basis[i] = n + i;
+}
+
+}  // namespace lpamd

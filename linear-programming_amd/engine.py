@@ -1,0 +1,240 @@
+"""ctypes binding of the lpamd C ABI (include/lpamd.h), one method per entry point.
+
+Mirrors the tableau part of the reference's LPModel surface (reference
+lp.h:64-106): ToTableau -> TableauEngine.upload, TableauPivot -> pivot,
+TableauSimplexInitialize -> phase1, TableauSimplexSolve -> solve,
+GetTableauSimplexOptimum/Solution -> objective_constant / column_values.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+# reference lp.h:32-37 (enum Result) + LIMIT, lp.h:74-79 (PivotingStrategy)
+ERROR, UNBOUNDED, NOSOLUTION, SOLVED, LIMIT = 0, 1, 2, 3, 4
+MAX_COST, MAX_REDUCTION = 2, 3
+STRATEGY = {"max_cost": MAX_COST, "max_reduction": MAX_REDUCTION}
+CANDIDATE_BYTES = 32
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LpamdError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "lib", "liblpamd.so")
+
+
+def library():
+    """Loads liblpamd.so; raises if it has not been built (no fallback path)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise LpamdError("%s is missing: build it with `make` (or __graft_entry__.build())" % path)
+    L = ctypes.CDLL(path)
+    i32, i64, u64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint64, ctypes.c_void_p
+    P = ctypes.POINTER
+    sig = {
+        "lpamd_exchange_bytes": (i64, [i64]),
+        "lpamd_last_error": (ctypes.c_char_p, []),
+        "lpamd_version": (ctypes.c_char_p, []),
+        "lpamd_create": (ctypes.c_int, [P(vp), i64, i64, i32, i32, vp]),
+        "lpamd_destroy": (ctypes.c_int, [vp]),
+        "lpamd_upload": (ctypes.c_int, [vp, vp, i64, vp, vp]),
+        "lpamd_fill_synthetic": (ctypes.c_int, [vp, i64, u64]),
+        "lpamd_download": (ctypes.c_int, [vp, vp, i64, vp, vp]),
+        "lpamd_read_column": (ctypes.c_int, [vp, i64, vp]),
+        "lpamd_read_row": (ctypes.c_int, [vp, i64, vp]),
+        "lpamd_write_objective": (ctypes.c_int, [vp, vp]),
+        "lpamd_basis_of_row": (ctypes.c_int, [vp, vp]),
+        "lpamd_need_init": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_price_max_cost": (ctypes.c_int, [vp, P(i64)]),
+        "lpamd_ratio_test": (ctypes.c_int, [vp, i64, P(i64), P(i64)]),
+        "lpamd_price_max_reduction": (ctypes.c_int, [vp, P(i64), P(i64), P(i64)]),
+        "lpamd_pivot": (ctypes.c_int, [vp, i64, i64, i64]),
+        "lpamd_phase1": (ctypes.c_int, [vp, i32, P(i32)]),
+        "lpamd_solve": (ctypes.c_int, [vp, i32, i64, P(i32), P(i64)]),
+        "lpamd_run_pivots": (ctypes.c_int, [vp, i32, i64, P(i32), P(i64)]),
+        "lpamd_column_values": (ctypes.c_int, [vp, vp]),
+        "lpamd_objective_constant": (ctypes.c_int, [vp, P(ctypes.c_double)]),
+        "lpamd_pivot_count": (ctypes.c_int, [vp, P(i64)]),
+        "lpamd_trace": (ctypes.c_int, [vp, vp, vp, i64, P(i64)]),
+        "lpamd_set_profiling": (ctypes.c_int, [vp, i32]),
+        "lpamd_update_stats": (ctypes.c_int, [vp, P(ctypes.c_double), P(i64), P(i64)]),
+        "lpamd_local_candidate": (ctypes.c_int, [vp, i32, vp]),
+        "lpamd_select_candidate": (ctypes.c_int, [vp, i32, vp, i32, P(i64), P(i64), P(i32), P(i32)]),
+        "lpamd_export_column": (ctypes.c_int, [vp, i64, vp]),
+        "lpamd_apply_pivot": (ctypes.c_int, [vp, i32, i64, i64, vp]),
+        "lpamd_poll": (ctypes.c_int, [vp, P(i32)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)   # AttributeError here = header and library disagree
+        fn.restype, fn.argtypes = res, args
+    L._lpamd_symbols = tuple(sig)
+    _LIB = L
+    return L
+
+
+def _ck(rc):
+    if rc != 0:
+        raise LpamdError("lpamd error %d: %s" % (rc, library().lpamd_last_error().decode()))
+
+
+class TableauEngine:
+    """Device-resident m x (N+2) tableau shard on the current HIP device."""
+
+    def __init__(self, m, N, rank=0, world=1, stream=None):
+        self.L = library()
+        self.m, self.N, self.rank, self.world = int(m), int(N), int(rank), int(world)
+        self.h = ctypes.c_void_p()
+        _ck(self.L.lpamd_create(ctypes.byref(self.h), self.m, self.N, self.rank, self.world,
+                                ctypes.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self.h:
+            self.L.lpamd_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data ----
+    def upload(self, T, obj, is_basic):
+        T = np.asfortranarray(T, dtype=np.float64)
+        assert T.shape == (self.m, self.N + 2), (T.shape, self.m, self.N)
+        obj = np.ascontiguousarray(obj, dtype=np.float64)
+        is_basic = np.ascontiguousarray(is_basic, dtype=np.uint8)
+        assert obj.shape == (self.N + 2,) and is_basic.shape == (self.N + 2,)
+        _ck(self.L.lpamd_upload(self.h, T.ctypes.data, max(T.strides[1] // 8, self.m), obj.ctypes.data, is_basic.ctypes.data))
+
+    def fill_synthetic(self, n_struct, seed):
+        _ck(self.L.lpamd_fill_synthetic(self.h, int(n_struct), int(seed)))
+
+    def download(self):
+        T = np.zeros((self.m, self.N + 2), dtype=np.float64, order="F")
+        obj = np.zeros(self.N + 2, dtype=np.float64)
+        is_basic = np.zeros(self.N + 2, dtype=np.uint8)
+        _ck(self.L.lpamd_download(self.h, T.ctypes.data, self.m, obj.ctypes.data, is_basic.ctypes.data))
+        return T, obj, is_basic
+
+    def read_column(self, j):
+        out = np.zeros(self.m, dtype=np.float64)
+        _ck(self.L.lpamd_read_column(self.h, int(j), out.ctypes.data))
+        return out
+
+    def read_row(self, i):
+        out = np.zeros(self.N + 2, dtype=np.float64)
+        _ck(self.L.lpamd_read_row(self.h, int(i), out.ctypes.data))
+        return out
+
+    def write_objective(self, obj):
+        obj = np.ascontiguousarray(obj, dtype=np.float64)
+        assert obj.shape == (self.N + 2,)
+        _ck(self.L.lpamd_write_objective(self.h, obj.ctypes.data))
+
+    def basis_of_row(self):
+        out = np.zeros(self.m, dtype=np.int64)
+        _ck(self.L.lpamd_basis_of_row(self.h, out.ctypes.data))
+        return out
+
+    # ---- single steps ----
+    def need_init(self):
+        v = ctypes.c_int32()
+        _ck(self.L.lpamd_need_init(self.h, ctypes.byref(v)))
+        return bool(v.value)
+
+    def price_max_cost(self):
+        e = ctypes.c_int64()
+        _ck(self.L.lpamd_price_max_cost(self.h, ctypes.byref(e)))
+        return e.value
+
+    def ratio_test(self, e):
+        r, d = ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_ratio_test(self.h, int(e), ctypes.byref(r), ctypes.byref(d)))
+        return r.value, d.value
+
+    def price_max_reduction(self):
+        e, r, d = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_price_max_reduction(self.h, ctypes.byref(e), ctypes.byref(r), ctypes.byref(d)))
+        return e.value, r.value, d.value
+
+    def pivot(self, d, e, r):
+        _ck(self.L.lpamd_pivot(self.h, int(d), int(e), int(r)))
+
+    def phase1(self, strategy):
+        res = ctypes.c_int32()
+        _ck(self.L.lpamd_phase1(self.h, int(strategy), ctypes.byref(res)))
+        return res.value
+
+    def solve(self, strategy, max_pivots=-1):
+        res, n = ctypes.c_int32(), ctypes.c_int64()
+        _ck(self.L.lpamd_solve(self.h, int(strategy), int(max_pivots), ctypes.byref(res), ctypes.byref(n)))
+        return res.value, n.value
+
+    def run_pivots(self, strategy, k):
+        res, n = ctypes.c_int32(), ctypes.c_int64()
+        _ck(self.L.lpamd_run_pivots(self.h, int(strategy), int(k), ctypes.byref(res), ctypes.byref(n)))
+        return res.value, n.value
+
+    def column_values(self):
+        x = np.zeros(self.N + 2, dtype=np.float64)
+        _ck(self.L.lpamd_column_values(self.h, x.ctypes.data))
+        return x
+
+    def objective_constant(self):
+        v = ctypes.c_double()
+        _ck(self.L.lpamd_objective_constant(self.h, ctypes.byref(v)))
+        return v.value
+
+    def pivot_count(self):
+        n = ctypes.c_int64()
+        _ck(self.L.lpamd_pivot_count(self.h, ctypes.byref(n)))
+        return n.value
+
+    def trace(self):
+        n = self.pivot_count()
+        e = np.zeros(max(n, 1), dtype=np.int64)
+        r = np.zeros(max(n, 1), dtype=np.int64)
+        got = ctypes.c_int64()
+        _ck(self.L.lpamd_trace(self.h, e.ctypes.data, r.ctypes.data, n, ctypes.byref(got)))
+        return list(zip(e[:n].tolist(), r[:n].tolist()))
+
+    def set_profiling(self, on):
+        _ck(self.L.lpamd_set_profiling(self.h, 1 if on else 0))
+
+    def update_stats(self):
+        ms, n, act = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_update_stats(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(act)))
+        return ms.value, n.value, act.value
+
+    # ---- multi-GPU steps (device pointers are plain ints, e.g. tensor.data_ptr()) ----
+    def local_candidate(self, strategy, cand_ptr):
+        _ck(self.L.lpamd_local_candidate(self.h, int(strategy), ctypes.c_void_p(cand_ptr)))
+
+    def select_candidate(self, strategy, cands_ptr):
+        e, r, owner, res = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+        _ck(self.L.lpamd_select_candidate(self.h, int(strategy), ctypes.c_void_p(cands_ptr), self.world,
+                                          ctypes.byref(e), ctypes.byref(r), ctypes.byref(owner), ctypes.byref(res)))
+        return e.value, r.value, owner.value, res.value
+
+    def export_column(self, e, xbuf_ptr):
+        _ck(self.L.lpamd_export_column(self.h, int(e), ctypes.c_void_p(xbuf_ptr)))
+
+    def apply_pivot(self, strategy, e, r, xbuf_ptr):
+        _ck(self.L.lpamd_apply_pivot(self.h, int(strategy), int(e), int(r), ctypes.c_void_p(xbuf_ptr)))
+
+    def poll(self):
+        res = ctypes.c_int32()
+        _ck(self.L.lpamd_poll(self.h, ctypes.byref(res)))
+        return res.value
+
+    def exchange_doubles(self):
+        return int(self.L.lpamd_exchange_bytes(self.m)) // 8

@@ -70,7 +70,7 @@ class DenseTableau:
     """Column-major dense tableau driven by the C core."""
 
     def __init__(self, T, obj, is_basic, N, trace_cap=1 << 16, basis_of_row=None):
-        T = np.asfortranarray(T, dtype=np.float64)
+        T = np.array(T, dtype=np.float64, order="F", copy=True)   # never alias the caller's matrix
         self.T = T
         self.m, self.ncols = T.shape
         assert self.ncols == N + 2
