@@ -135,6 +135,10 @@ int lpamd_local_candidate(lpamd_engine* eng, int32_t strategy, void* cand_dev);
  *    *result = LPAMD_LIMIT while running, else the terminal Result. */
 int lpamd_select_candidate(lpamd_engine* eng, int32_t strategy, const void* cands_dev, int32_t world,
                            int64_t* e, int64_t* r, int32_t* owner_rank, int32_t* result);
+/*    The fold itself, on `world` records in HOST memory; touches no device, so it
+ *    also runs on a machine without a GPU.  winner_out (32 B) may be NULL. */
+int lpamd_fold_candidates(int32_t strategy, const void* records_host, int32_t world, int64_t N, int64_t* e, int64_t* r,
+                          int32_t* owner_rank, int32_t* result, void* winner_out);
 /* 3. owner of column e: copy it into the exchange buffer (asynchronous). */
 int lpamd_export_column(lpamd_engine* eng, int64_t e, void* xbuf_dev);
 /* 4. caller broadcasts xbuf from the owner; every rank: ratio test on the

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -55,6 +56,10 @@ struct lpamd_engine {
   Shape sh{};
   int32_t ncl = 0;          // nloc + 1
   int32_t n_slabs = 0;
+  int32_t update_grid = 2048;   // workgroups of the rank-1 update
+  bool update_nt = false;       // nontemporal loads/stores: shards beyond the Infinity Cache
+  int32_t update_unroll_cap = 16;
+  bool update_prec = true;      // load col' together with the tableau batch
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -157,10 +162,19 @@ int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
   return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
 }
 
+template <int kUnroll>
+void launch_update(lpamd_engine* e, int grid, bool nt) {
+#define LPAMD_LAUNCH_UPDATE(NT, PC)                                                                                         \
+  hipLaunchKernelGGL((k_update<kUnroll, NT, PC>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, \
+                     e->rowp, e->active, e->st)
+  if (nt && e->update_prec) LPAMD_LAUNCH_UPDATE(true, true);
+  else if (nt) LPAMD_LAUNCH_UPDATE(true, false);
+  else if (e->update_prec) LPAMD_LAUNCH_UPDATE(false, true);
+  else LPAMD_LAUNCH_UPDATE(false, false);
+#undef LPAMD_LAUNCH_UPDATE
+}
+
 int enqueue_update(lpamd_engine* e) {
-  const int n_rc = (e->n_slabs + kUpdateSlabs - 1) / kUpdateSlabs;
-  const int cstride = std::max(1, 2048 / n_rc);
-  const int grid = cstride * n_rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->ev_used + 2 > e->ev.size()) {
@@ -174,8 +188,15 @@ int enqueue_update(lpamd_engine* e) {
     e1 = e->ev[e->ev_used++];
     HIP_TRY(hipEventRecord(e0, e->stream));
   }
-  hipLaunchKernelGGL(k_update, dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->n_slabs, e->colp, e->rowp,
-                     e->active, e->st);
+  // accesses in flight per lane: as many as one column allows, at most 16
+  const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);   // 512-row slabs = 256 vectors of 16 B
+  const int grid = e->update_grid;
+  if (n_slabs >= 32) launch_update<32>(e, grid, e->update_nt);
+  else if (n_slabs >= 16) launch_update<16>(e, grid, e->update_nt);
+  else if (n_slabs >= 8) launch_update<8>(e, grid, e->update_nt);
+  else if (n_slabs >= 4) launch_update<4>(e, grid, e->update_nt);
+  else if (n_slabs >= 2) launch_update<2>(e, grid, e->update_nt);
+  else launch_update<1>(e, grid, e->update_nt);
   LP_TRY(check_launch("k_update"));
   if (e->profiling) HIP_TRY(hipEventRecord(e1, e->stream));
   return LPAMD_OK;
@@ -282,6 +303,15 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   e->sh.world = world;
   e->ncl = (int32_t)nloc + 1;
   e->n_slabs = (int32_t)(e->sh.lda / kSlabRows);
+  // Measured on MI355X (bench.py sweeps, profiles/): shards beyond the 256 MiB Infinity
+  // Cache stream 11 % faster with nt loads/stores, shards inside it 13 % slower; one
+  // workgroup per column (up to 8192) balances short columns best, long columns do not care.
+  e->update_nt = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
+  e->update_grid = std::max(1, std::min<int32_t>(e->ncl, 8192));
+  if (const char* env = getenv("LPAMD_UPDATE_NT")) e->update_nt = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_UPDATE_UNROLL")) e->update_unroll_cap = std::max(1, atoi(env));
+  if (const char* env = getenv("LPAMD_UPDATE_PREC")) e->update_prec = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_UPDATE_GRID")) e->update_grid = std::max(1, atoi(env));
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
   } else {
@@ -703,6 +733,41 @@ int lpamd_local_candidate(lpamd_engine* e, int32_t strategy, void* cand_dev) {
   return enqueue_pricing(e, strategy, (Candidate*)cand_dev);
 }
 
+// Pure host fold over the gathered records (no device access, callable without a
+// GPU): MAX_COST keeps the largest reduced cost (reference
+// lp_simplex_tableau.cc:190-198), MAX_REDUCTION the largest c_j * min-ratio among
+// columns that have an eligible row (reference lp_simplex_tableau.cc:310-325 /
+// 353-362); ties go to the lowest global column id in both.
+int lpamd_fold_candidates(int32_t strategy, const void* records_host, int32_t world, int64_t N, int64_t* col, int64_t* r,
+                          int32_t* owner_rank, int32_t* result, void* winner_out) {
+  if (!records_host || world <= 0 || !col || !r || !owner_rank || !result)
+    return set_err(LPAMD_E_ARG, "fold_candidates: bad arguments");
+  if (strategy != LPAMD_MAX_COST && strategy != LPAMD_MAX_REDUCTION)
+    return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+  const Candidate* c = (const Candidate*)records_host;
+  *col = -1;
+  *r = -1;
+  *owner_rank = -1;
+  Candidate best{-DBL_MAX, -1, -1, 0.0};
+  bool any = false;
+  for (int32_t k = 0; k < world; k++) {
+    if (c[k].gcol < 0) continue;
+    any = true;
+    if (strategy == LPAMD_MAX_REDUCTION && c[k].row < 0) continue;
+    if (best.gcol < 0 || c[k].key > best.key || (c[k].key == best.key && c[k].gcol < best.gcol)) best = c[k];
+  }
+  if (best.gcol < 0) {
+    *result = any ? LPAMD_UNBOUNDED : LPAMD_SOLVED;   // reference lp_simplex_tableau.cc:365-373 / 201-205
+    return LPAMD_OK;
+  }
+  if (winner_out) std::memcpy(winner_out, &best, sizeof(Candidate));
+  *col = best.gcol;
+  *r = best.row;
+  *owner_rank = (int32_t)(ordinal_of(best.gcol, N) % world);
+  *result = LPAMD_LIMIT;
+  return LPAMD_OK;
+}
+
 int lpamd_select_candidate(lpamd_engine* e, int32_t strategy, const void* cands_dev, int32_t world, int64_t* col, int64_t* r,
                            int32_t* owner_rank, int32_t* result) {
   CHECK_LOADED(e);
@@ -715,24 +780,11 @@ int lpamd_select_candidate(lpamd_engine* e, int32_t strategy, const void* cands_
   *r = -1;
   *owner_rank = -1;
   if (e->h_st.status != ST_RUNNING) { *result = status_to_result(e->h_st.status); return LPAMD_OK; }
-  Candidate best{-DBL_MAX, -1, -1, 0.0};
-  bool any = false;
-  for (const Candidate& k : c) {
-    if (k.gcol < 0) continue;
-    any = true;
-    if (strategy == LPAMD_MAX_REDUCTION && k.row < 0) continue;
-    if (best.gcol < 0 || k.key > best.key || (k.key == best.key && k.gcol < best.gcol)) best = k;
-  }
-  if (best.gcol < 0) {
-    *result = any ? LPAMD_UNBOUNDED : LPAMD_SOLVED;   // reference lp_simplex_tableau.cc:365-373 / 201-205
-    return LPAMD_OK;
-  }
+  Candidate best;
+  LP_TRY(lpamd_fold_candidates(strategy, c.data(), world, e->sh.N, col, r, owner_rank, result, &best));
+  if (*result != LPAMD_LIMIT) return LPAMD_OK;
   HIP_TRY(hipMemcpyAsync(e->cand, &best, sizeof(Candidate), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));   // `best` is a stack object
-  *col = best.gcol;
-  *r = best.row;
-  *owner_rank = (int32_t)(ordinal_of(best.gcol, e->sh.N) % e->sh.world);
-  *result = LPAMD_LIMIT;
   return LPAMD_OK;
 }
 

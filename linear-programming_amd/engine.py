@@ -68,6 +68,7 @@ def library():
         "lpamd_update_stats": (ctypes.c_int, [vp, P(ctypes.c_double), P(i64), P(i64)]),
         "lpamd_local_candidate": (ctypes.c_int, [vp, i32, vp]),
         "lpamd_select_candidate": (ctypes.c_int, [vp, i32, vp, i32, P(i64), P(i64), P(i32), P(i32)]),
+        "lpamd_fold_candidates": (ctypes.c_int, [i32, vp, i32, i64, P(i64), P(i64), P(i32), P(i32), vp]),
         "lpamd_export_column": (ctypes.c_int, [vp, i64, vp]),
         "lpamd_apply_pivot": (ctypes.c_int, [vp, i32, i64, i64, vp]),
         "lpamd_poll": (ctypes.c_int, [vp, P(i32)]),
@@ -83,6 +84,18 @@ def library():
 def _ck(rc):
     if rc != 0:
         raise LpamdError("lpamd error %d: %s" % (rc, library().lpamd_last_error().decode()))
+
+
+def fold_candidates(strategy, records, world, N):
+    """Global winner among per-rank candidate records (a float64 array of 4*world
+    words laid out as {key, gcol:int64, row:int64, ce}); pure host code."""
+    rec = np.ascontiguousarray(records, dtype=np.float64)
+    assert rec.size == 4 * world
+    e, r, owner, res = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int32(), ctypes.c_int32()
+    win = np.zeros(4, dtype=np.float64)
+    _ck(library().lpamd_fold_candidates(int(strategy), rec.ctypes.data, int(world), int(N), ctypes.byref(e), ctypes.byref(r),
+                                        ctypes.byref(owner), ctypes.byref(res), win.ctypes.data))
+    return e.value, r.value, owner.value, res.value, win
 
 
 class TableauEngine:

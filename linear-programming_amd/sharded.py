@@ -1,0 +1,91 @@
+"""Column-sharded pivot loop over several GPUs, one process per GPU.
+
+Each rank owns the tableau columns whose ordinal is congruent to its rank
+(round-robin deal, so the dense columns stay balanced while the basis drifts)
+plus a replica of the right-hand-side column.  One iteration of the reference's
+main loop (reference lp_simplex_tableau.cc:181-377) needs two exchanges:
+
+  1. all-gather of one 32-byte candidate record per rank, folded identically on
+     every rank with the reference's lowest-index tie-break (pricing);
+  2. broadcast of the entering column (m doubles) from the rank that owns it.
+
+Everything else (ratio test on the broadcast column against the local RHS
+replica, row gather, rank-1 update of the local shard) is rank-local and
+bit-identical across ranks, so no further traffic is needed.
+`torch.distributed` carries both exchanges: backend "nccl" (RCCL over xGMI) on
+GPUs, "gloo" in the CPU tests, which plug in a host stand-in for the shard.
+"""
+import torch
+import torch.distributed as dist
+
+from . import engine as _eng
+
+
+class EngineShard:
+    """Adapter: a TableauEngine shard addressed with torch tensors."""
+
+    def __init__(self, m, N, rank, world, device):
+        self.device = device
+        stream = torch.cuda.current_stream(device).cuda_stream
+        self.eng = _eng.TableauEngine(m, N, rank, world, stream=stream)
+        self.m, self.N, self.rank, self.world = m, N, rank, world
+
+    def exchange_doubles(self):
+        return self.eng.exchange_doubles()
+
+    def new_buffer(self, n_doubles):
+        return torch.zeros(n_doubles, dtype=torch.float64, device=self.device)
+
+    def local_candidate(self, strategy, cand):
+        self.eng.local_candidate(strategy, cand.data_ptr())
+
+    def select_candidate(self, strategy, cands):
+        return self.eng.select_candidate(strategy, cands.data_ptr())
+
+    def export_column(self, e, xbuf):
+        self.eng.export_column(e, xbuf.data_ptr())
+
+    def apply_pivot(self, strategy, e, r, xbuf):
+        self.eng.apply_pivot(strategy, e, r, xbuf.data_ptr())
+
+    def poll(self):
+        return self.eng.poll()
+
+
+class ShardedSolver:
+    """Drives one shard per rank through the pivot loop."""
+
+    def __init__(self, shard, group=None):
+        self.shard = shard
+        self.group = group
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        assert self.world == shard.world and self.rank == shard.rank
+        self.cand = shard.new_buffer(4)
+        self.cands = shard.new_buffer(4 * self.world)
+        self.xbuf = shard.new_buffer(shard.exchange_doubles())
+        self.trace = []
+
+    def run_pivots(self, strategy, k):
+        """At most k pivots (k < 0: until termination).  Returns (Result, pivots done)."""
+        sh = self.shard
+        done = 0
+        while k < 0 or done < k:
+            sh.local_candidate(strategy, self.cand)
+            if self.world > 1:
+                dist.all_gather_into_tensor(self.cands, self.cand, group=self.group)
+            else:
+                self.cands.copy_(self.cand)
+            e, r, owner, res = sh.select_candidate(strategy, self.cands)
+            if res != _eng.LIMIT:
+                return res, done
+            if owner == self.rank:
+                sh.export_column(e, self.xbuf)
+            if self.world > 1:
+                src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+                dist.broadcast(self.xbuf, src=src, group=self.group)
+            sh.apply_pivot(strategy, e, r, self.xbuf)
+            self.trace.append(e)
+            done += 1
+        res = sh.poll()
+        return res, done
