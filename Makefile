@@ -21,14 +21,18 @@ HOST_SRCS := $(wildcard $(CSRC)/host/*.cc)
 host: engine
 	@if [ -n "$(HOST_SRCS)" ]; then $(MAKE) --no-print-directory host-bins; fi
 
-host-bins: $(BINDIR)/solver $(BINDIR)/lp_host_probe
-HOST_LIB_SRCS := $(filter-out %/solver_main.cc %/host_probe_main.cc,$(HOST_SRCS))
+host-bins: $(BINDIR)/solver $(BINDIR)/lp_host_probe $(BINDIR)/lp_host_selftest
+HOST_LIB_SRCS := $(filter-out %_main.cc,$(HOST_SRCS))
 $(BINDIR)/solver: $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h) $(LIBDIR)/liblpamd.so
 	@mkdir -p $(BINDIR)
 	g++ $(CXXFLAGS) -o $@ $(HOST_LIB_SRCS) $(CSRC)/host/solver_main.cc -L$(LIBDIR) -llpamd -Wl,-rpath,'$$ORIGIN/../lib'
 $(BINDIR)/lp_host_probe: $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h) $(LIBDIR)/liblpamd.so
 	@mkdir -p $(BINDIR)
 	g++ $(CXXFLAGS) -o $@ $(HOST_LIB_SRCS) $(CSRC)/host/host_probe_main.cc -L$(LIBDIR) -llpamd -Wl,-rpath,'$$ORIGIN/../lib'
+
+$(BINDIR)/lp_host_selftest: $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h) $(LIBDIR)/liblpamd.so
+	@mkdir -p $(BINDIR)
+	g++ $(CXXFLAGS) -o $@ $(HOST_LIB_SRCS) $(CSRC)/host/host_selftest_main.cc -L$(LIBDIR) -llpamd -Wl,-rpath,'$$ORIGIN/../lib'
 
 oracle:
 	$(MAKE) -C oracle

@@ -1,0 +1,88 @@
+// solver <input-file> [solver-algo] [pivot-strategy]
+// Command line of the reference's solver.cc for the tableau path: parses the LP
+// text file, runs `simplex_tableau` on the GPU engine and prints the optimum
+// followed by `name = value` lines (reference solver.cc:160-171).  Algorithms
+// other than simplex_tableau belong to the reference's CPU-only solvers and are
+// rejected.  A file ending in .mps is first converted the way the reference's
+// tools/mps_load.py does.
+#include <algorithm>
+#include <cctype>
+#include <fstream>
+#include <iostream>
+
+#include "lp_model.h"
+#include "lp_text.h"
+#include "mps_text.h"
+
+namespace {
+
+std::string Lower(std::string s) {
+  std::transform(s.begin(), s.end(), s.begin(), [](unsigned char c) { return (char)std::tolower(c); });
+  return s;
+}
+
+LPModel::PivotingStrategy ParsePivotingStrategy(const std::string& text) {
+  const std::string t = Lower(text);
+  if (t == "smallest_subscript") return LPModel::SMALLEST_SUBSCRIPT;
+  if (t == "max_cost") return LPModel::MAX_COST;
+  if (t == "max_reduction") return LPModel::MAX_REDUCTION;
+  return LPModel::PIVOTING_UNKNOWN;
+}
+
+bool EndsWith(const std::string& s, const std::string& suffix) {
+  return s.size() >= suffix.size() && s.compare(s.size() - suffix.size(), suffix.size(), suffix) == 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 2) {
+    std::cout << "usage: " << argv[0] << " input-file [solver-algo] [pivot-strategy]\n";
+    return -1;
+  }
+  const std::string path = argv[1];
+  const std::string algo = argc >= 3 ? Lower(argv[2]) : "simplex_tableau";
+  LPModel::PivotingStrategy strategy = LPModel::MAX_COST;
+  if (argc >= 4) strategy = ParsePivotingStrategy(argv[3]);
+  bool print_trace = false;
+  for (int i = 4; i < argc; i++) print_trace |= std::string(argv[i]) == "--trace";
+
+  Parser parser;
+  Model model = {{}, OptimizationObject(FLOAT)};
+  if (EndsWith(Lower(path), ".mps")) {
+    model = parser.Parse(MpsToLpText(path));
+  } else {
+    std::ifstream file(path);
+    model = parser.Parse(file);
+  }
+  // An LP whose constraints mention no FLOAT variable is an integer program
+  // (reference solver.cc:79-99); that path is not part of this engine.
+  bool any_float = false;
+  for (auto& con : model.constraints)
+    for (auto& term : con.expression.variable_coeff) any_float |= term.first.type == FLOAT;
+  if (!any_float || algo != "simplex_tableau") {
+    std::cerr << "only `simplex_tableau` on continuous LPs runs on the GPU engine (got algo `" << algo << "`)\n";
+    std::cout << "Error\n";
+    return 2;
+  }
+
+  LPModel lp_model(model);
+  lp_model.SetPivotingStrategy(strategy);
+  lp_model.ToStandardForm();
+  lp_model.ToSlackForm();
+  lp_model.ToTableau();
+  const Result result = lp_model.TableauSimplexSolve();
+  if (result == SOLVED) {
+    std::cout << lp_model.GetTableauSimplexOptimum().ToString() << "\n";
+    for (auto& entry : lp_model.GetTableauSimplexSolution()) std::cout << entry.first.ToString() << " = " << entry.second.ToString() << "\n";
+  } else if (result == NOSOLUTION) {
+    std::cout << "No Solution\n";
+  } else if (result == UNBOUNDED) {
+    std::cout << "Unbounded\n";
+  } else {
+    std::cout << "Error\n";
+  }
+  if (print_trace)
+    for (auto& p : lp_model.TableauPivotTrace()) std::cerr << "pivot " << p.first << " " << p.second << "\n";
+  return 0;
+}

@@ -805,15 +805,6 @@ int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r,
   return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, (const double*)xbuf_dev, -1);
 }
 
-// Debug aid: scalars of the last pivot set-up {e, r, d, a, ce, f, g, n_active}.
-int lpamd_debug_state(lpamd_engine* e, double* out8) {
-  CHECK_LOADED(e);
-  LP_TRY(pull_state(e));
-  out8[0] = (double)e->h_st.e; out8[1] = (double)e->h_st.r; out8[2] = (double)e->h_st.d; out8[3] = e->h_st.a;
-  out8[4] = e->h_st.ce; out8[5] = e->h_st.f; out8[6] = e->h_st.g; out8[7] = (double)e->h_st.n_active;
-  return LPAMD_OK;
-}
-
 int lpamd_poll(lpamd_engine* e, int32_t* result) {
   CHECK_LOADED(e);
   LP_TRY(pull_state(e));

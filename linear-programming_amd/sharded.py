@@ -24,10 +24,15 @@ from . import engine as _eng
 class EngineShard:
     """Adapter: a TableauEngine shard addressed with torch tensors."""
 
-    def __init__(self, m, N, rank, world, device):
+    def __init__(self, m, N, rank, world, device, stream=None):
         self.device = device
-        stream = torch.cuda.current_stream(device).cuda_stream
-        self.eng = _eng.TableauEngine(m, N, rank, world, stream=stream)
+        # The engine's kernels, the buffer copies and the collectives must share ONE
+        # stream so that they are ordered without host synchronisation.  torch's
+        # default stream has handle 0, which the C ABI reads as "create your own",
+        # so the shard brings an explicit side stream; callers run the exchange
+        # steps under `with torch.cuda.stream(shard.stream)`.
+        self.stream = stream if stream is not None else torch.cuda.Stream(device)
+        self.eng = _eng.TableauEngine(m, N, rank, world, stream=self.stream.cuda_stream)
         self.m, self.N, self.rank, self.world = m, N, rank, world
 
     def exchange_doubles(self):
@@ -58,8 +63,9 @@ class ShardedSolver:
     def __init__(self, shard, group=None):
         self.shard = shard
         self.group = group
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.use_dist = dist.is_available() and dist.is_initialized()   # collectives also run for a world of one
+        self.rank = dist.get_rank(group) if self.use_dist else 0
+        self.world = dist.get_world_size(group) if self.use_dist else 1
         assert self.world == shard.world and self.rank == shard.rank
         self.cand = shard.new_buffer(4)
         self.cands = shard.new_buffer(4 * self.world)
@@ -68,11 +74,18 @@ class ShardedSolver:
 
     def run_pivots(self, strategy, k):
         """At most k pivots (k < 0: until termination).  Returns (Result, pivots done)."""
+        stream = getattr(self.shard, "stream", None)
+        if stream is None:
+            return self._run(strategy, k)
+        with torch.cuda.stream(stream):
+            return self._run(strategy, k)
+
+    def _run(self, strategy, k):
         sh = self.shard
         done = 0
         while k < 0 or done < k:
             sh.local_candidate(strategy, self.cand)
-            if self.world > 1:
+            if self.use_dist:
                 dist.all_gather_into_tensor(self.cands, self.cand, group=self.group)
             else:
                 self.cands.copy_(self.cand)
@@ -81,7 +94,7 @@ class ShardedSolver:
                 return res, done
             if owner == self.rank:
                 sh.export_column(e, self.xbuf)
-            if self.world > 1:
+            if self.use_dist:
                 src = owner if self.group is None else dist.get_global_rank(self.group, owner)
                 dist.broadcast(self.xbuf, src=src, group=self.group)
             sh.apply_pivot(strategy, e, r, self.xbuf)

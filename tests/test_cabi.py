@@ -1,0 +1,82 @@
+"""CPU: the C-ABI library loads and exports every symbol that include/lpamd.h
+declares; the host-only entry points work without a GPU; device entry points fail
+loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cases import ROOT
+from conftest import lpamd_pkg
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lpamd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lpamd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lp = lpamd_pkg()
+    lib = ctypes.CDLL(lp.library_path())
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), "include/lpamd.h declares %s but liblpamd.so does not export it" % n
+    # and the Python binding binds every one of them
+    assert set(names) <= set(lp.library()._lpamd_symbols)
+
+
+def test_version_and_exchange_size():
+    lp = lpamd_pkg()
+    L = lp.library()
+    assert L.lpamd_version().startswith(b"lpamd")
+    assert L.lpamd_exchange_bytes(1) == 512 * 8
+    assert L.lpamd_exchange_bytes(4096) == 4096 * 8
+    assert L.lpamd_exchange_bytes(4097) == 4608 * 8
+
+
+def _rec(key, gcol, row, ce):
+    a = np.zeros(4, dtype=np.float64)
+    a[0], a[3] = key, ce
+    a.view(np.int64)[1], a.view(np.int64)[2] = gcol, row
+    return a
+
+
+def test_fold_candidates_max_cost_rule():
+    from importlib import import_module
+    eng = import_module("linear-programming_amd.engine")
+    N, world = 10, 4
+    recs = np.concatenate([_rec(3.0, 5, -1, 3.0), _rec(7.0, 6, -1, 7.0), _rec(7.0, 2, -1, 7.0), _rec(0, -1, -1, 0)])
+    e, r, owner, res, win = eng.fold_candidates(eng.MAX_COST, recs, world, N)
+    assert (e, res) == (2, eng.LIMIT)           # largest cost, lowest column on the tie
+    assert owner == 2 % world
+    assert win[0] == 7.0 and win.view(np.int64)[1] == 2
+    none = np.concatenate([_rec(0, -1, -1, 0)] * world)
+    assert eng.fold_candidates(eng.MAX_COST, none, world, N)[3] == eng.SOLVED
+    # artificial column N+1 has ordinal N
+    art = np.concatenate([_rec(1.0, N + 1, -1, 1.0)] + [_rec(0, -1, -1, 0)] * 3)
+    e, r, owner, res, _ = eng.fold_candidates(eng.MAX_COST, art, world, N)
+    assert (e, owner, res) == (N + 1, N % world, eng.LIMIT)
+
+
+def test_fold_candidates_max_reduction_rule():
+    from importlib import import_module
+    eng = import_module("linear-programming_amd.engine")
+    N, world = 10, 3
+    recs = np.concatenate([_rec(-1e308, 1, -1, 2.0), _rec(4.0, 7, 3, 1.0), _rec(4.0, 4, 9, 2.0)])
+    e, r, owner, res, _ = eng.fold_candidates(eng.MAX_REDUCTION, recs, world, N)
+    assert (e, r, owner, res) == (4, 9, 1, eng.LIMIT)   # rows required; tie -> lowest column
+    norow = np.concatenate([_rec(-1e308, 1, -1, 2.0), _rec(0, -1, -1, 0), _rec(-1e308, 5, -1, 1.0)])
+    assert eng.fold_candidates(eng.MAX_REDUCTION, norow, world, N)[3] == eng.UNBOUNDED
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lp = lpamd_pkg()
+    with pytest.raises(lp.LpamdError, match="no HIP device"):
+        lp.TableauEngine(4, 8)

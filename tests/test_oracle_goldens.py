@@ -1,0 +1,97 @@
+"""CPU: pins the oracle (oracle/) on every tableau-path golden the reference ships
+and on the tableau snapshots of its unit tests."""
+import os
+
+import numpy as np
+import pytest
+
+from cases import GOLDEN, all_cases, case_golden, case_text
+from oracle import lp_frontend as fe
+from oracle import lp_oracle as lo
+
+
+@pytest.mark.parametrize("name,strategy", all_cases())
+def test_oracle_reproduces_reference_golden(name, strategy):
+    out, dt = lo.solve_text(case_text(name), strategy)
+    assert out.rstrip("\n") == case_golden(name, strategy).rstrip("\n")
+
+
+def _text(n):
+    return fe.read_text(os.path.join(GOLDEN, "lp", "test%d.txt" % n))
+
+
+def test_unit_snapshot_to_tableau():   # reference lp_test.cc:472-490
+    tab = fe.build_tableau(_text(9))
+    assert fe.print_tableau(tab.T, tab.obj, tab.names, tab.N) == (
+        "-0.800000 * x1 + -0.500000 * x2 + -0.900000 * x3 + -1.500000 * x4\n"
+        "-1.000000 * base0 + 1000.000000 * x1 + 1500.000000 * x2 + 1750.000000 * x3 + 3250.000000 * x4 + -4000.000000\n"
+        "-1.000000 * base1 + 0.600000 * x1 + 0.270000 * x2 + 0.680000 * x3 + 0.300000 * x4 + -1.000000\n"
+        "-1.000000 * base2 + 17.500000 * x1 + 7.700000 * x2 + 30.000000 * x4 + -30.000000\n")
+
+
+def test_unit_snapshot_two_pivots():   # reference lp_test.cc:492-513
+    tab, dt = lo.from_text(_text(3))
+    ix = tab.index
+    dt.pivot(ix["base0"], ix["x1"], 0)
+    assert fe.print_tableau(dt.T, dt.obj, tab.names, tab.N) == (
+        "-0.500000 * base0 + 0.500000 * x2 + 6.000000\n"
+        "-0.500000 * base0 + -1.000000 * x1 + -0.500000 * x2 + 6.000000\n"
+        "0.500000 * base0 + -1.000000 * base1 + -1.500000 * x2 + 3.000000\n")
+    dt.pivot(ix["base1"], ix["x2"], 1)
+    assert fe.print_tableau(dt.T, dt.obj, tab.names, tab.N) == (
+        "-0.333333 * base0 + -0.333333 * base1 + 7.000000\n"
+        "-0.666667 * base0 + 0.333333 * base1 + -1.000000 * x1 + 5.000000\n"
+        "0.333333 * base0 + -0.666667 * base1 + -1.000000 * x2 + 2.000000\n")
+
+
+def test_unit_snapshot_phase1():   # reference lp_test.cc:231-267 (needs the ties-to-later-row MinReduce)
+    tab, dt = lo.from_text(_text(4))
+    assert dt.phase1(lo.MAX_COST) == lo.SOLVED
+    assert fe.print_tableau(dt.T, dt.obj, tab.names, tab.N) == (
+        "-4.000000 * base0 + -1.000000 * base1 + -5.000000\n"
+        "0.333333 * base0 + 0.333333 * base1 + -1.000000 * x1 + 0.666667\n"
+        "0.666667 * base0 + -0.333333 * base1 + -1.000000 * x2 + 0.333333\n"
+        "-2.000000 * base0 + 1.000000 * base1 + -1.000000 * base2 + 1.000000\n")
+    assert dt.solve(lo.MAX_COST) == lo.SOLVED
+    x = dt.column_values()
+    assert (-1) * dt.obj[tab.N] == 5.0   # opt_reverted
+    assert abs(x[tab.index["x1"]] - 2 / 3) < 1e-6 and abs(x[tab.index["x2"]] - 1 / 3) < 1e-6
+
+
+def test_unit_solve_test3():   # reference lp_test.cc:134-148
+    out, _ = lo.solve_text(_text(3), "max_cost")
+    assert out == "-7.000000\nx1 = 5.000000\nx2 = 2.000000\n"
+
+
+@pytest.mark.parametrize("name,strategy", [("test16", "max_cost"), ("test17", "max_reduction"), ("adlittle", "max_cost"),
+                                            ("kb2", "max_reduction"), ("israel", "max_cost")])
+def test_fast_options_do_not_change_results(name, strategy):
+    """skip_zero_cols / fast_basis (used for the timed CPU baseline) give the same
+    trace and the same bits as the plain dense restatement."""
+    tab, a = lo.from_text(case_text(name))
+    _, b = lo.from_text(case_text(name))
+    b.s.skip_zero_cols = 1
+    ra = a.solve(lo.STRATEGY[strategy])
+    rb = b.solve(lo.STRATEGY[strategy])
+    assert ra == rb == lo.SOLVED
+    assert a.trace() == b.trace()
+    assert np.array_equal(a.T.view(np.uint64), b.T.view(np.uint64))
+    assert np.array_equal(a.obj.view(np.uint64), b.obj.view(np.uint64))
+
+
+def test_synthetic_fast_basis_matches_row_scan():
+    a = lo.DenseTableau.synthetic(48, 100, 3)
+    b = lo.DenseTableau.synthetic(48, 100, 3)
+    b.s.fast_basis = 1
+    b.s.skip_zero_cols = 1
+    for strat in (lo.MAX_COST,):
+        assert a.solve(strat) == b.solve(strat) == lo.SOLVED
+    assert a.trace() == b.trace()
+    assert np.array_equal(a.T.view(np.uint64), b.T.view(np.uint64))
+
+
+def test_unbounded_infeasible_empty_objective():
+    assert lo.solve_text("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n")[0] == "Unbounded\n"
+    assert lo.solve_text("max x1\nst\nx1 <= 1\nx1 >= 2\nx1 >= 0\n")[0] == "No Solution\n"
+    # degenerate: objective mentions no constrained variable -> already optimal
+    assert lo.solve_text("max 0 * x1\nst\nx1 <= 1\nx1 >= 0\n")[0].startswith("0.000000\n")

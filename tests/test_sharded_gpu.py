@@ -1,0 +1,164 @@
+"""GPU: the column-shard entry points of the C ABI.  Two shards (rank 0 and 1 of a
+world of 2) live on the one GPU of the test box and exchange their candidate
+records and the pivot column through plain device copies, which exercises the
+same kernels and index maps a multi-GPU run uses; results must equal the oracle
+bit for bit."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from cases import case_text
+from oracle import lp_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def run_loopback(shards, strategy, eng, max_pivots=-1):
+    dev = shards[0].device
+    world = len(shards)
+    cand = [s.new_buffer(4) for s in shards]
+    cands = shards[0].new_buffer(4 * world)
+    xbuf = shards[0].new_buffer(shards[0].exchange_doubles())
+    trace, done = [], 0
+    while max_pivots < 0 or done < max_pivots:
+        for s, c in zip(shards, cand):
+            s.local_candidate(strategy, c)
+        for k, c in enumerate(cand):
+            cands[4 * k: 4 * k + 4].copy_(c)
+        sel = [s.select_candidate(strategy, cands) for s in shards]
+        assert all(x == sel[0] for x in sel), "ranks disagree on the entering column"
+        e, r, owner, res = sel[0]
+        if res != eng.LIMIT:
+            return res, trace
+        shards[owner].export_column(e, xbuf)
+        for s in shards:
+            s.apply_pivot(strategy, e, r, xbuf)
+        trace.append(e)
+        done += 1
+    return shards[0].poll(), trace
+
+
+def assemble(shards, m, N):
+    T = np.zeros((m, N + 2), order="F")
+    obj = np.zeros(N + 2)
+    basic = np.zeros(N + 2, dtype=np.uint8)
+    L = shards[0].eng.L
+    rhs = []
+    for s in shards:
+        L.lpamd_download(s.eng.h, T.ctypes.data, m, obj.ctypes.data, basic.ctypes.data)
+        rhs.append(T[:, N].copy())
+    return T, obj, basic, rhs
+
+
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_two_shards_one_gpu_synthetic(lpamd, strategy, world):
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    m, n, seed = 700, 1300, 11
+    stream = torch.cuda.Stream(dev)     # one stream for every shard of the loop-back "node"
+    shards = [sharded.EngineShard(m, n + m, r, world, dev, stream=stream) for r in range(world)]
+    for s in shards:
+        s.eng.fill_synthetic(n, seed)
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    with torch.cuda.stream(stream):
+        res, trace = run_loopback(shards, eng.STRATEGY[strategy], eng)
+    torch.cuda.synchronize()
+    assert res == dt.solve(lo.STRATEGY[strategy]) == eng.SOLVED
+    assert trace == [e for e, _ in dt.trace()]
+    for s in shards:                      # every rank recorded the full (e, r) trace
+        assert s.eng.trace() == dt.trace()
+    T, obj, basic, rhs = assemble(shards, m, n + m)
+    assert all(np.array_equal(bits(rhs[0]), bits(x)) for x in rhs), "RHS replicas diverged"
+    assert np.array_equal(bits(T), bits(dt.T))
+    assert np.array_equal(bits(obj), bits(dt.obj))
+    assert np.array_equal(basic[: dt.N], dt.is_basic[: dt.N])
+    for s in shards:
+        s.eng.close()
+
+
+def test_two_shards_uploaded_lp_without_phase1(lpamd):
+    """test12 needs no phase 1: upload the same host matrix to both shards."""
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    tab, dt = lo.from_text(case_text("test12"))
+    assert not dt.need_init()
+    stream = torch.cuda.Stream(dev)
+    shards = [sharded.EngineShard(tab.m, tab.N, r, 2, dev, stream=stream) for r in range(2)]
+    for s in shards:
+        s.eng.upload(tab.T, tab.obj, tab.is_basic)
+    with torch.cuda.stream(stream):
+        res, _ = run_loopback(shards, eng.MAX_COST, eng)
+    assert res == dt.solve(lo.MAX_COST) == eng.SOLVED
+    assert shards[0].eng.trace() == dt.trace() == shards[1].eng.trace()
+    T, obj, _, _ = assemble(shards, tab.m, tab.N)
+    assert np.array_equal(bits(T), bits(dt.T)) and np.array_equal(bits(obj), bits(dt.obj))
+
+
+def test_single_rank_sharded_solver_equals_device_loop(lpamd):
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    m, n, seed = 300, 500, 4
+    shard = sharded.EngineShard(m, n + m, 0, 1, dev)
+    shard.eng.fill_synthetic(n, seed)
+    solver = sharded.ShardedSolver(shard)
+    res, done = solver.run_pivots(eng.MAX_COST, 25)
+    assert (res, done) == (eng.LIMIT, 25)
+    ref = lpamd.TableauEngine(m, n + m)
+    ref.fill_synthetic(n, seed)
+    ref.run_pivots(eng.MAX_COST, 25)
+    assert shard.eng.trace() == ref.trace()
+    a, b = shard.eng.download(), ref.download()
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
+
+
+def test_phase1_is_rejected_on_shards(lpamd):
+    eng = importlib.import_module("linear-programming_amd.engine")
+    e = lpamd.TableauEngine(8, 20, rank=0, world=2)
+    e.fill_synthetic(12, 1)
+    with pytest.raises(lpamd.LpamdError, match="world == 1"):
+        e.solve(eng.MAX_COST)
+
+
+def test_rccl_collectives_single_rank(lpamd):
+    """World of one over the nccl (= RCCL) backend: the all-gather and the broadcast
+    of the sharded loop run for real on the GPU."""
+    import socket
+    import torch.distributed as dist
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        m, n, seed = 300, 500, 9
+        shard = sharded.EngineShard(m, n + m, 0, 1, dev)
+        shard.eng.fill_synthetic(n, seed)
+        solver = sharded.ShardedSolver(shard)
+        assert solver.use_dist
+        res, done = solver.run_pivots(eng.MAX_REDUCTION, 12)
+        res2, done2 = solver.run_pivots(eng.MAX_COST, -1)
+        torch.cuda.synchronize()
+        dt = lo.DenseTableau.synthetic(m, n, seed)
+        assert dt.solve(lo.MAX_REDUCTION, max_pivots=12) == lo.LIMIT
+        assert dt.solve(lo.MAX_COST) == lo.SOLVED
+        assert (res, done, res2) == (eng.LIMIT, 12, eng.SOLVED)
+        assert shard.eng.trace() == dt.trace()
+        T, obj, _ = shard.eng.download()
+        assert np.array_equal(bits(T), bits(dt.T)) and np.array_equal(bits(obj), bits(dt.obj))
+    finally:
+        dist.destroy_process_group()
