@@ -75,6 +75,9 @@ struct lpamd_engine {
   double* cmin = nullptr;
   int64_t* crow = nullptr;
   Candidate* cand = nullptr;
+  double* part_v = nullptr;     // [2 * kMaxPartials]: pricing partials, then ratio partials
+  int64_t* part_i = nullptr;
+  int32_t n_price_part = 1, n_ratio_part = 1, n_row_blocks = 1;
   PivotState* st = nullptr;
   int64_t* trace = nullptr;
   int64_t trace_cap = 0;
@@ -145,10 +148,17 @@ int check_launch(const char* what) {
 }
 
 // --- enqueue helpers (no synchronisation) ---------------------------------
+int enqueue_price_partial(lpamd_engine* e) {
+  hipLaunchKernelGGL(k_price_partial, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->obj, e->is_basic, e->sh, e->st,
+                     e->part_v, e->part_i);
+  return check_launch("k_price_partial");
+}
+
 int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
   if (strategy == LPAMD_MAX_COST) {
-    hipLaunchKernelGGL(k_price_max_cost, dim3(1), dim3(kSelectThreads), 0, e->stream, e->obj, e->is_basic, e->sh, e->st, out);
-    return check_launch("k_price_max_cost");
+    LP_TRY(enqueue_price_partial(e));
+    hipLaunchKernelGGL(k_price_fold, dim3(1), dim3(kPartialThreads), 0, e->stream, e->part_v, e->part_i, e->n_price_part, e->sh, e->st, out);
+    return check_launch("k_price_fold");
   }
   if (strategy == LPAMD_MAX_REDUCTION) {
     hipLaunchKernelGGL(k_pr_columns, dim3(e->sh.nloc), dim3(256), 0, e->stream, e->T, e->obj, e->is_basic, e->sh, e->st,
@@ -202,24 +212,51 @@ int enqueue_update(lpamd_engine* e) {
   return LPAMD_OK;
 }
 
-// set-up + row gather + rank-1 update for the candidate in `cand`
-int enqueue_pivot(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override) {
-  if (find_row)
-    hipLaunchKernelGGL(k_pivot_setup<true>, dim3(1), dim3(kSelectThreads), 0, e->stream, e->T, e->sh, cand, xcol, e->basis,
-                       d_override, e->st, e->colp);
+int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, const double* xcol) {
+  double* rv = e->part_v + kMaxPartials;
+  int64_t* ri = e->part_i + kMaxPartials;
+  if (fold_price)
+    hipLaunchKernelGGL(k_ratio_partial<true>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->part_v,
+                       e->part_i, e->n_price_part, cand, xcol, rv, ri);
   else
-    hipLaunchKernelGGL(k_pivot_setup<false>, dim3(1), dim3(kSelectThreads), 0, e->stream, e->T, e->sh, cand, xcol, e->basis,
-                       d_override, e->st, e->colp);
-  LP_TRY(check_launch("k_pivot_setup"));
-  hipLaunchKernelGGL(k_prep, dim3((e->ncl + 255) / 256), dim3(256), 0, e->stream, e->T, e->sh, e->obj, e->is_basic, e->basis,
-                     e->rowp, e->active, e->st, e->trace, e->trace_cap);
-  LP_TRY(check_launch("k_prep"));
+    hipLaunchKernelGGL(k_ratio_partial<false>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->part_v,
+                       e->part_i, e->n_price_part, cand, xcol, rv, ri);
+  return check_launch("k_ratio_partial");
+}
+
+// pivot set-up + row gather (one launch), then the rank-1 update
+int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override) {
+  const double* rv = e->part_v + kMaxPartials;
+  const int64_t* ri = e->part_i + kMaxPartials;
+  const int grid = e->n_row_blocks + (e->ncl + kPartialThreads - 1) / kPartialThreads;
+  if (find_row)
+    hipLaunchKernelGGL(k_pivot_finalize<true>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
+                       e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
+                       e->trace, e->trace_cap);
+  else
+    hipLaunchKernelGGL(k_pivot_finalize<false>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
+                       e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
+                       e->trace, e->trace_cap);
+  LP_TRY(check_launch("k_pivot_finalize"));
   return enqueue_update(e);
 }
 
+// ratio test (if the row is not known yet) + set-up + update for the candidate in `cand`
+int enqueue_pivot(lpamd_engine* e, bool find_row, Candidate* cand, const double* xcol, int64_t d_override) {
+  if (find_row) LP_TRY(enqueue_ratio_partial(e, false, cand, xcol));
+  return enqueue_finalize_update(e, find_row, cand, xcol, d_override);
+}
+
+// One iteration of the main loop on one GPU: 4 launches for MAX_COST (pricing
+// partials, ratio partials, set-up + row gather, update), 4 for MAX_REDUCTION.
 int enqueue_iteration(lpamd_engine* e, int strategy) {
+  if (strategy == LPAMD_MAX_COST) {
+    LP_TRY(enqueue_price_partial(e));
+    LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
+    return enqueue_finalize_update(e, true, e->cand, nullptr, -1);
+  }
   LP_TRY(enqueue_pricing(e, strategy, e->cand));
-  return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, nullptr, -1);
+  return enqueue_finalize_update(e, false, e->cand, nullptr, -1);
 }
 
 // Device-resident main loop: at most `budget` pivots (budget < 0: none).
@@ -235,9 +272,15 @@ int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
     int64_t todo = batch;
     if (budget >= 0) todo = std::min<int64_t>(batch, e->h_st.max_iter - e->h_st.iter);
     LP_TRY(ensure_trace(e, e->h_st.iter + todo));
+    const int64_t before = e->h_st.iter;
     for (int64_t k = 0; k < todo; k++) LP_TRY(enqueue_iteration(e, strategy));
     LP_TRY(pull_state(e));
     if (e->h_st.status != ST_RUNNING) break;
+    if (e->h_st.iter == before) {   // running but no pivot applied: never spin on the GPU
+      e->h_st.status = ST_ERROR;
+      set_err(LPAMD_E_STATE, "pivot loop made no progress");
+      break;
+    }
     if (budget >= 0 && e->h_st.iter >= e->h_st.max_iter) { e->h_st.status = ST_LIMIT; break; }
     batch = std::min<int64_t>(batch * 2, 1024);
   }
@@ -334,6 +377,12 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
+  HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
+  HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 2 * kMaxPartials));
+  // partial reductions: about 2048 columns / 1024 rows per workgroup, at most kMaxPartials workgroups
+  e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 2047) / 2048));
+  e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + 1023) / 1024));
+  e->n_row_blocks = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
   HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
   HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda, e->stream));
   HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));
@@ -349,7 +398,7 @@ int lpamd_destroy(lpamd_engine* e) {
   hipSetDevice(e->device);
   hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
-  void* ptrs[] = {e->T, e->obj, e->obj_saved, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->cand, e->st, e->trace};
+  void* ptrs[] = {e->T, e->obj, e->obj_saved, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->cand, e->part_v, e->part_i, e->st, e->trace};
   for (void* p : ptrs)
     if (p) hipFree(p);
   if (e->own_stream) hipStreamDestroy(e->stream);
@@ -474,6 +523,7 @@ static int begin_step(lpamd_engine* e) {
   LP_TRY(pull_state(e));
   e->h_st.status = ST_RUNNING;
   e->h_st.max_iter = std::numeric_limits<int64_t>::max();
+  e->h_st.n_active = 0;
   return push_state(e);
 }
 
@@ -509,12 +559,18 @@ int lpamd_ratio_test(lpamd_engine* e, int64_t col, int64_t* r, int64_t* d) {
   LP_TRY(begin_step(e));
   Candidate c{0.0, col, -1, 0.0};
   HIP_TRY(hipMemcpyAsync(e->cand, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
-  hipLaunchKernelGGL(k_pivot_setup<true>, dim3(1), dim3(kSelectThreads), 0, e->stream, e->T, e->sh, e->cand, (const double*)nullptr,
-                     e->basis, (int64_t)-1, e->st, e->colp);
-  LP_TRY(check_launch("k_pivot_setup"));
-  LP_TRY(pull_state(e));
-  if (e->h_st.status == ST_UNBOUNDED) { *r = -1; *d = -1; }
-  else { *r = e->h_st.r; *d = e->h_st.d; }
+  LP_TRY(enqueue_ratio_partial(e, false, e->cand, nullptr));
+  std::vector<double> rv(e->n_ratio_part);
+  std::vector<int64_t> ri(e->n_ratio_part);
+  LP_TRY(read_local(e, e->part_v + kMaxPartials, rv.data(), sizeof(double) * rv.size()));
+  LP_TRY(read_local(e, e->part_i + kMaxPartials, ri.data(), sizeof(int64_t) * ri.size()));
+  double bv = 0.0;
+  int64_t bi = -1;
+  for (size_t k = 0; k < rv.size(); k++)   // same rule as the device fold: smaller ratio, then lower row
+    if (ri[k] >= 0 && (bi < 0 || rv[k] < bv || (rv[k] == bv && ri[k] < bi))) { bv = rv[k]; bi = ri[k]; }
+  *r = bi;
+  *d = -1;
+  if (bi >= 0) LP_TRY(read_local(e, e->basis + bi, d, sizeof(int64_t)));
   return LPAMD_OK;
 }
 

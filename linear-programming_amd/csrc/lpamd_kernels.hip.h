@@ -25,6 +25,8 @@ namespace lpamd {
 constexpr int kSlabRows = 512;        // rows covered by one 256-thread block with 16 B per lane
 constexpr int kUpdateThreads = 256;
 constexpr int kSelectThreads = 1024;  // single-workgroup selection kernels
+constexpr int kPartialThreads = 256;  // multi-workgroup partial reductions
+constexpr int kMaxPartials = 256;
 constexpr int kWave = 64;
 
 // device-side status: 0 while running, otherwise (reference Result value + 1)
@@ -101,22 +103,61 @@ __device__ __forceinline__ void block_arg(double& v, int64_t& i, double* s_v, in
 }
 
 // ------------------------------------------------------------------ pricing
+// Folds up to kMaxPartials (value, index) partial results; every thread of the
+// workgroup gets the winner.  Used redundantly by all workgroups of the kernel
+// that consumes the partials, which avoids an extra launch or a grid barrier.
+template <bool kMax, int kThreads>
+__device__ __forceinline__ void fold_partials(const double* __restrict__ pv, const int64_t* __restrict__ pi, int n,
+                                              double& v, int64_t& i, double* s_v, int64_t* s_i) {
+  v = kMax ? -DBL_MAX : DBL_MAX;
+  i = -1;
+  for (int k = threadIdx.x; k < n; k += kThreads) {
+    if (kMax) take_max(v, i, pv[k], pi[k]); else take_min(v, i, pv[k], pi[k]);
+  }
+  block_arg<kMax, kThreads>(v, i, s_v, s_i);
+  if (threadIdx.x == 0) { s_v[0] = v; s_i[0] = i; }
+  __syncthreads();
+  v = s_v[0];
+  i = s_i[0];
+  __syncthreads();
+}
+
 // MAX_COST pricing (reference lp_simplex_tableau.cc:188-198): largest positive
-// reduced cost over non-basic columns, lowest column index on ties.
-__global__ __launch_bounds__(kSelectThreads) void k_price_max_cost(
+// reduced cost over non-basic columns, lowest column index on ties.  Stage 1:
+// every workgroup reduces a strided share of the objective row with a
+// wavefront-level arg-max and leaves one partial (value, local column).
+__global__ __launch_bounds__(kPartialThreads) void k_price_partial(
     const double* __restrict__ obj, const uint8_t* __restrict__ is_basic, Shape sh,
-    const PivotState* __restrict__ st, Candidate* __restrict__ cand) {
-  __shared__ double s_v[kSelectThreads / kWave];
-  __shared__ int64_t s_i[kSelectThreads / kWave];
+    PivotState* __restrict__ st, double* __restrict__ pv, int64_t* __restrict__ pi) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   double bv = -DBL_MAX;
   int64_t bi = -1;
-  for (int l = threadIdx.x; l < sh.nloc; l += kSelectThreads) {
+  for (int l = blockIdx.x * kPartialThreads + threadIdx.x; l < sh.nloc; l += gridDim.x * kPartialThreads) {
     if (is_basic[l]) continue;
     const double c = obj[l];
     if (is_pos(c) && c > bv) { bv = c; bi = l; }
   }
-  block_arg<true, kSelectThreads>(bv, bi, s_v, s_i);
+  block_arg<true, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    pv[blockIdx.x] = bv;
+    pi[blockIdx.x] = bi;
+    if (blockIdx.x == 0) st->n_active = 0;   // consumed by the update of the previous pivot, refilled by this one
+  }
+}
+
+// Stage 2 when the candidate has to leave the GPU (multi-GPU exchange, single
+// step API): one workgroup folds the partials into a candidate record.
+__global__ __launch_bounds__(kPartialThreads) void k_price_fold(
+    const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_part, Shape sh,
+    const PivotState* __restrict__ st, Candidate* __restrict__ cand) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  double bv;
+  int64_t bi;
+  fold_partials<true, kPartialThreads>(pv, pi, n_part, bv, bi, s_v, s_i);
   if (threadIdx.x == 0) {
     Candidate c;
     c.key = bv;
@@ -162,7 +203,7 @@ __global__ __launch_bounds__(256) void k_pr_columns(
 // with row = -1 (=> unbounded).
 __global__ __launch_bounds__(kSelectThreads) void k_pr_select(
     const double* __restrict__ obj, const double* __restrict__ cmin, const int64_t* __restrict__ crow,
-    Shape sh, const PivotState* __restrict__ st, Candidate* __restrict__ cand) {
+    Shape sh, PivotState* __restrict__ st, Candidate* __restrict__ cand) {
   __shared__ double s_v[kSelectThreads / kWave];
   __shared__ int64_t s_i[kSelectThreads / kWave];
   if (st->status != ST_RUNNING) return;
@@ -177,6 +218,8 @@ __global__ __launch_bounds__(kSelectThreads) void k_pr_select(
     if (score > bv) { bv = score; bi = l; }
   }
   block_arg<true, kSelectThreads>(bv, bi, s_v, s_i);
+  if (st->iter >= st->max_iter) { if (threadIdx.x == 0) st->status = ST_LIMIT; return; }
+  if (threadIdx.x == 0) st->n_active = 0;
   // first candidate = smallest local index: reduce with key = -index
   fv = fi < 0 ? 0.0 : -(double)fi;
   block_arg<true, kSelectThreads>(fv, fi, s_v, s_i);
@@ -193,82 +236,105 @@ __global__ __launch_bounds__(kSelectThreads) void k_pr_select(
   }
 }
 
-// ------------------------------------------------------- ratio test + set-up
-// One workgroup.  kFindRow: the MAX_COST ratio test (reference
-// lp_simplex_tableau.cc:207-227) as an LDS-staged arg-min over the pivot
-// column (taken from the local shard, or from `xcol` when the column was
-// broadcast by its owner); otherwise the row comes with the candidate.
-// Then fixes the scalars of TableauPivot (reference lp_simplex_tableau.cc:33-44)
-// and writes col' (pivot column with col'[r] = 1 + a) into colp.
+// ------------------------------------------------------- ratio test
+// MAX_COST ratio test (reference lp_simplex_tableau.cc:207-227), stage 1: every
+// workgroup stages its rows' ratios b_i / (-T_ie) through an LDS arg-min (lowest
+// row on ties) and leaves one partial.  The pivot column is the local column of
+// the entering variable, or `xcol` when its owner broadcast it.
+// kFoldPrice: the entering column is first folded from the pricing partials
+// (single-GPU loop); otherwise it comes with the candidate record.
+template <bool kFoldPrice>
+__global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
+    const double* __restrict__ T, Shape sh, PivotState* __restrict__ st,
+    const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
+    Candidate* __restrict__ cand, const double* __restrict__ xcol,
+    double* __restrict__ rv, int64_t* __restrict__ ri) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (st->iter >= st->max_iter) { if (lead) st->status = ST_LIMIT; return; }
+  int64_t e;
+  if (kFoldPrice) {
+    double ce;
+    int64_t l;
+    fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
+    if (l < 0) { if (lead) st->status = ST_SOLVED; return; }
+    e = gcol_of(l * sh.world + sh.rank, sh.N);
+    if (lead) {
+      Candidate c;
+      c.key = ce; c.gcol = e; c.row = -1; c.ce = ce;
+      *cand = c;
+    }
+  } else {
+    e = cand->gcol;
+    if (e < 0) { if (lead) st->status = ST_SOLVED; return; }
+  }
+  const double* __restrict__ col = xcol ? xcol : T + (ordinal_of(e, sh.N) / sh.world) * sh.lda;
+  const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
+    const double a = col[i];
+    if ((float)a > -1e-6f) continue;   // skips _IsZero and _IsNonNegative entries alike
+    const double ratio = rhs[i] / (-a);
+    if (bv > ratio) { bv = ratio; bi = i; }
+  }
+  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    rv[blockIdx.x] = bv;
+    ri[blockIdx.x] = bi;
+    if (blockIdx.x == 0) st->n_active = 0;
+  }
+}
+
+// ------------------------------------------------ pivot set-up + row gather
+// One launch prepares everything the rank-1 update needs.  Every workgroup first
+// folds the ratio partials (or takes the row from the candidate) and derives the
+// scalars of TableauPivot (reference lp_simplex_tableau.cc:33-44) redundantly:
+//   a = T[r][e], f = -1/a, g = c_e * f.
+// Workgroups [0, n_row_blocks) then write their slice of col' (the pivot column
+// with col'[r] = 1 + a) into colp; the others handle 256 local columns each (RHS
+// replica included): row'[j] = T[r][j] * f, obj[j] = flush(obj[j] + T[r][j] * g),
+// and the list of columns the update has to touch (row' != 0).  The first column
+// workgroup also does the bookkeeping of reference lp_simplex_tableau.cc:16-28.
 template <bool kFindRow>
-__global__ __launch_bounds__(kSelectThreads) void k_pivot_setup(
-    const double* __restrict__ T, Shape sh, const Candidate* __restrict__ cand,
-    const double* __restrict__ xcol, const int64_t* __restrict__ basis, int64_t d_override,
-    PivotState* __restrict__ st, double* __restrict__ colp) {
-  __shared__ double s_v[kSelectThreads / kWave];
-  __shared__ int64_t s_i[kSelectThreads / kWave];
-  __shared__ int64_t s_r;
+__global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
+    const double* __restrict__ T, Shape sh, const Candidate* __restrict__ cand, const double* __restrict__ xcol,
+    const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
+    int64_t d_override, PivotState* __restrict__ st, double* __restrict__ colp,
+    double* __restrict__ obj, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
+    double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const Candidate c = *cand;
-  if (st->iter >= st->max_iter) { if (threadIdx.x == 0) st->status = ST_LIMIT; return; }
-  if (c.gcol < 0) { if (threadIdx.x == 0) st->status = ST_SOLVED; return; }
-  const int64_t eo = ordinal_of(c.gcol, sh.N);
-  const double* __restrict__ col = xcol ? xcol : T + (eo / sh.world) * sh.lda;
-  const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+  if (c.gcol < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_SOLVED; return; }   // no entering column
   int64_t r;
   if (kFindRow) {
-    double bv = DBL_MAX;
-    int64_t bi = -1;
-    for (int64_t i = threadIdx.x; i < sh.m; i += kSelectThreads) {
-      const double a = col[i];
-      if ((float)a > -1e-6f) continue;   // skips _IsZero and _IsNonNegative entries alike
-      const double ratio = rhs[i] / (-a);
-      if (bv > ratio) { bv = ratio; bi = i; }
-    }
-    block_arg<false, kSelectThreads>(bv, bi, s_v, s_i);
-    if (threadIdx.x == 0) s_r = bi;
-    __syncthreads();
-    r = s_r;
+    double best;
+    fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r, s_v, s_i);
   } else {
     r = c.row;
   }
-  if (r < 0) { if (threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
+  if (r < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
+  const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
+  const double* __restrict__ col = xcol ? xcol : T + (eo / sh.world) * sh.lda;
   const double a = col[r];
-  if (threadIdx.x == 0) {
-    const double f = -1.0 / a;                       // lp_simplex_tableau.cc:40
-    st->e = c.gcol;
-    st->r = r;
-    st->d = d_override >= 0 ? d_override : basis[r];
-    st->a = a;
-    st->ce = c.ce;
-    st->f = f;
-    st->g = __dmul_rn(c.ce, f);                      // lp_simplex_tableau.cc:34-35
-    st->n_active = 0;
+  const double f = -1.0 / a;                         // lp_simplex_tableau.cc:40
+  const double g = __dmul_rn(c.ce, f);               // lp_simplex_tableau.cc:34-35
+  if ((int)blockIdx.x < n_row_blocks) {
+    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads)
+      colp[i] = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
+    return;
   }
-  for (int64_t i = threadIdx.x; i < sh.m; i += kSelectThreads)
-    colp[i] = (i == r) ? __dadd_rn(1.0, a) : col[i]; // lp_simplex_tableau.cc:41-44
-}
-
-// ------------------------------------------------------------ row gather
-// One thread per local column (RHS replica included): row' = T[r][.] * f, the
-// objective-row update obj += T[r][.] * g (reference lp_simplex_tableau.cc:33-40),
-// and the list of columns the rank-1 update has to touch (row' != 0).  Thread 0
-// also does the bookkeeping of reference lp_simplex_tableau.cc:16-28.
-__global__ __launch_bounds__(256) void k_prep(
-    const double* __restrict__ T, Shape sh, double* __restrict__ obj, uint8_t* __restrict__ is_basic,
-    int64_t* __restrict__ basis, double* __restrict__ rowp, int32_t* __restrict__ active,
-    PivotState* __restrict__ st, int64_t* __restrict__ trace, int64_t trace_cap) {
-  if (st->status != ST_RUNNING) return;
-  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  const int l = ((int)blockIdx.x - n_row_blocks) * kPartialThreads + threadIdx.x;
   const int ncl = sh.nloc + 1;
-  const int64_t e = st->e, r = st->r, d = st->d;
-  const double f = st->f, g = st->g;
   bool act = false;
   if (l < ncl) {
     const double t = T[(int64_t)l * sh.lda + r];
     const double rp = __dmul_rn(t, f);
-    double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g)));
-    const int64_t eo = ordinal_of(e, sh.N);
+    double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g)));   // :36
     if (l < sh.nloc && eo % sh.world == sh.rank && eo / sh.world == l) o = 0.0;   // :37
     obj[l] = o;
     rowp[l] = rp;
@@ -285,13 +351,15 @@ __global__ __launch_bounds__(256) void k_prep(
     if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
   }
   if (l == 0) {
-    const int64_t eo = ordinal_of(e, sh.N);
+    const int64_t d = d_override >= 0 ? d_override : basis[r];
     if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
     if (d >= 0 && d != sh.N) {
       const int64_t dord = ordinal_of(d, sh.N);
       if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
     }
     basis[r] = e;
+    st->e = e; st->r = r; st->d = d;
+    st->a = a; st->ce = c.ce; st->f = f; st->g = g;
     const int64_t it = st->iter;
     if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = r; }
     st->iter = it + 1;
