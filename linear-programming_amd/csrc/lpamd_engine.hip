@@ -78,6 +78,7 @@ struct lpamd_engine {
   double* part_v = nullptr;     // [2 * kMaxPartials]: pricing partials, then ratio partials
   int64_t* part_i = nullptr;
   int32_t n_price_part = 1, n_ratio_part = 1, n_row_blocks = 1;
+  bool price_partials_fresh = false;   // part_v/part_i[0..n_price_part) describe the current objective row and basis
   PivotState* st = nullptr;
   int64_t* trace = nullptr;
   int64_t trace_cap = 0;
@@ -137,6 +138,7 @@ int push_state(lpamd_engine* e) {
   return LPAMD_OK;
 }
 void reset_state(lpamd_engine* e) {
+  e->price_partials_fresh = false;
   std::memset(&e->h_st, 0, sizeof(PivotState));
   e->h_st.max_iter = std::numeric_limits<int64_t>::max();
 }
@@ -149,6 +151,7 @@ int check_launch(const char* what) {
 
 // --- enqueue helpers (no synchronisation) ---------------------------------
 int enqueue_price_partial(lpamd_engine* e) {
+  e->price_partials_fresh = true;
   hipLaunchKernelGGL(k_price_partial, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->obj, e->is_basic, e->sh, e->st,
                      e->part_v, e->part_i);
   return check_launch("k_price_partial");
@@ -156,7 +159,7 @@ int enqueue_price_partial(lpamd_engine* e) {
 
 int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
   if (strategy == LPAMD_MAX_COST) {
-    LP_TRY(enqueue_price_partial(e));
+    if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
     hipLaunchKernelGGL(k_price_fold, dim3(1), dim3(kPartialThreads), 0, e->stream, e->part_v, e->part_i, e->n_price_part, e->sh, e->st, out);
     return check_launch("k_price_fold");
   }
@@ -176,7 +179,7 @@ template <int kUnroll>
 void launch_update(lpamd_engine* e, int grid, bool nt) {
 #define LPAMD_LAUNCH_UPDATE(NT, PC)                                                                                         \
   hipLaunchKernelGGL((k_update<kUnroll, NT, PC>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, \
-                     e->rowp, e->active, e->st)
+                     e->rowp, e->active, e->st, e->sh, e->is_basic, e->basis)
   if (nt && e->update_prec) LPAMD_LAUNCH_UPDATE(true, true);
   else if (nt) LPAMD_LAUNCH_UPDATE(true, false);
   else if (e->update_prec) LPAMD_LAUNCH_UPDATE(false, true);
@@ -228,16 +231,17 @@ int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, con
 int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override) {
   const double* rv = e->part_v + kMaxPartials;
   const int64_t* ri = e->part_i + kMaxPartials;
-  const int grid = e->n_row_blocks + (e->ncl + kPartialThreads - 1) / kPartialThreads;
+  const int grid = e->n_row_blocks + e->n_price_part;   // column workgroups double as the next pricing partials
   if (find_row)
     hipLaunchKernelGGL(k_pivot_finalize<true>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
                        e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
-                       e->trace, e->trace_cap);
+                       e->trace, e->trace_cap, e->part_v, e->part_i);
   else
     hipLaunchKernelGGL(k_pivot_finalize<false>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
                        e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
-                       e->trace, e->trace_cap);
+                       e->trace, e->trace_cap, e->part_v, e->part_i);
   LP_TRY(check_launch("k_pivot_finalize"));
+  e->price_partials_fresh = true;
   return enqueue_update(e);
 }
 
@@ -251,7 +255,8 @@ int enqueue_pivot(lpamd_engine* e, bool find_row, Candidate* cand, const double*
 // partials, ratio partials, set-up + row gather, update), 4 for MAX_REDUCTION.
 int enqueue_iteration(lpamd_engine* e, int strategy) {
   if (strategy == LPAMD_MAX_COST) {
-    LP_TRY(enqueue_price_partial(e));
+    // the previous pivot's set-up kernel already left the pricing partials of this iteration
+    if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
     LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
     return enqueue_finalize_update(e, true, e->cand, nullptr, -1);
   }
@@ -380,8 +385,8 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
   HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 2 * kMaxPartials));
   // partial reductions: about 2048 columns / 1024 rows per workgroup, at most kMaxPartials workgroups
-  e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 2047) / 2048));
-  e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + 1023) / 1024));
+  e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 1 + kPartialThreads - 1) / kPartialThreads));
+  e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
   e->n_row_blocks = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
   HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
   HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda, e->stream));
@@ -492,6 +497,7 @@ int lpamd_read_row(const lpamd_engine* e, int64_t row, double* out) {
 
 int lpamd_write_objective(lpamd_engine* e, const double* obj) {
   CHECK_LOADED(e);
+  e->price_partials_fresh = false;
   if (!obj) return set_err(LPAMD_E_ARG, "write_objective: null");
   std::vector<double> h(e->ncl);
   for (int64_t l = 0; l < e->ncl; l++) h[l] = obj[global_of(e, l)];

@@ -26,7 +26,7 @@ constexpr int kSlabRows = 512;        // rows covered by one 256-thread block wi
 constexpr int kUpdateThreads = 256;
 constexpr int kSelectThreads = 1024;  // single-workgroup selection kernels
 constexpr int kPartialThreads = 256;  // multi-workgroup partial reductions
-constexpr int kMaxPartials = 256;
+constexpr int kMaxPartials = 2048;
 constexpr int kWave = 64;
 
 // device-side status: 0 while running, otherwise (reference Result value + 1)
@@ -296,15 +296,17 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
 // Workgroups [0, n_row_blocks) then write their slice of col' (the pivot column
 // with col'[r] = 1 + a) into colp; the others handle 256 local columns each (RHS
 // replica included): row'[j] = T[r][j] * f, obj[j] = flush(obj[j] + T[r][j] * g),
-// and the list of columns the update has to touch (row' != 0).  The first column
-// workgroup also does the bookkeeping of reference lp_simplex_tableau.cc:16-28.
+// the list of columns the update has to touch (row' != 0), and the pricing partial
+// of the NEXT iteration on the updated objective row (so the main loop needs no
+// separate pricing launch).  The first column workgroup records the pivot.
 template <bool kFindRow>
 __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
     const double* __restrict__ T, Shape sh, const Candidate* __restrict__ cand, const double* __restrict__ xcol,
     const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
     int64_t d_override, PivotState* __restrict__ st, double* __restrict__ colp,
-    double* __restrict__ obj, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
-    double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap) {
+    double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
+    double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
+    double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
@@ -328,36 +330,49 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
       colp[i] = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
     return;
   }
-  const int l = ((int)blockIdx.x - n_row_blocks) * kPartialThreads + threadIdx.x;
+  // column workgroups: strided over the local columns so that any width fits kMaxPartials workgroups
+  const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
   const int ncl = sh.nloc + 1;
-  bool act = false;
-  if (l < ncl) {
-    const double t = T[(int64_t)l * sh.lda + r];
-    const double rp = __dmul_rn(t, f);
-    double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g)));   // :36
-    if (l < sh.nloc && eo % sh.world == sh.rank && eo / sh.world == l) o = 0.0;   // :37
-    obj[l] = o;
-    rowp[l] = rp;
-    act = rp != 0.0;
-  }
-  // wave-aggregated append to the active list
-  const unsigned long long mask = __ballot(act);
-  if (mask) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int leader = __ffsll((long long)mask) - 1;
-    int base = 0;
-    if (lane == leader) base = atomicAdd(&st->n_active, __popcll(mask));
-    base = __shfl(base, leader, kWave);
-    if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
-  }
-  if (l == 0) {
-    const int64_t d = d_override >= 0 ? d_override : basis[r];
-    if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
-    if (d >= 0 && d != sh.N) {
-      const int64_t dord = ordinal_of(d, sh.N);
-      if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+  const int64_t d_now = d_override >= 0 ? d_override : basis[r];   // read before the bookkeeping thread overwrites basis[r]
+  const int64_t dord = (d_now >= 0 && d_now != sh.N) ? ordinal_of(d_now, sh.N) : -1;
+  const int l_e = (eo % sh.world == sh.rank) ? (int)(eo / sh.world) : -1;
+  const int l_d = (dord >= 0 && dord % sh.world == sh.rank) ? (int)(dord / sh.world) : -1;
+  double nbv = -DBL_MAX;   // pricing partial of the NEXT iteration, on the updated objective row
+  int64_t nbi = -1;
+  for (int l0 = cb * kPartialThreads; l0 < ncl; l0 += n_cb * kPartialThreads) {
+    const int l = l0 + threadIdx.x;
+    bool act = false;
+    if (l < ncl) {
+      const double t = T[(int64_t)l * sh.lda + r];
+      const double rp = __dmul_rn(t, f);
+      double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g)));   // :36
+      if (l == l_e) o = 0.0;                                     // :37
+      obj[l] = o;
+      rowp[l] = rp;
+      act = rp != 0.0;
+      if (l < sh.nloc) {
+        const bool basic_next = l == l_e ? true : (l == l_d ? false : is_basic[l] != 0);
+        if (!basic_next && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
+      }
     }
-    basis[r] = e;
+    // wave-aggregated append to the active list
+    const unsigned long long mask = __ballot(act);
+    if (mask) {
+      const int lane = threadIdx.x & (kWave - 1);
+      const int leader = __ffsll((long long)mask) - 1;
+      int base = 0;
+      if (lane == leader) base = atomicAdd(&st->n_active, __popcll(mask));
+      base = __shfl(base, leader, kWave);
+      if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+    }
+  }
+  block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
+  if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
+  const int l = cb * kPartialThreads + threadIdx.x;
+  if (l == 0) {
+    // The basis flags and basis[r] are read by every workgroup of this launch, so
+    // they are flipped by the update kernel that follows (k_update, workgroup 0).
+    const int64_t d = d_now;
     st->e = e; st->r = r; st->d = d;
     st->a = a; st->ce = c.ce; st->f = f; st->g = g;
     const int64_t it = st->iter;
@@ -405,8 +420,18 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
 
     double* __restrict__ T, int64_t lda, const double* __restrict__ colp,
     const double* __restrict__ rowp, const int32_t* __restrict__ active,
-    const PivotState* __restrict__ st) {
+    const PivotState* __restrict__ st, Shape sh, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
   if (st->status != ST_RUNNING) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // bookkeeping of reference lp_simplex_tableau.cc:16-28 for the pivot set up by k_pivot_finalize
+    const int64_t e = st->e, d = st->d, eo = ordinal_of(e, sh.N);
+    if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+    if (d >= 0 && d != sh.N) {
+      const int64_t dord = ordinal_of(d, sh.N);
+      if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+    }
+    basis[st->r] = e;
+  }
   const int n_active = st->n_active;
   const int n_vec = (int)(lda / 2);                  // 16-byte vectors per column, a multiple of 256
   const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
