@@ -34,6 +34,24 @@ DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
 
+def pmc_traffic(config, world):
+    """HBM bytes per k_update launch from the committed rocprofv3 PMC passes of this
+    same command (profiles/*/pmc_hbm_traffic_*.json: FETCH_SIZE doubled as gfx950
+    requires, plus WRITE_SIZE).  None when no pass exists for the configuration."""
+    import glob
+    if world != 1:
+        return None
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic_*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("config") == config:
+            best = d.get("traffic_bytes_per_launch")
+    return best
+
+
 def cpu_baseline(m, n, seed, strategy_name, budget_s=20.0):
     """Times the CPU restatement (oracle/, OpenMP over columns) on the same
     synthetic instance: a bounded number of pivots from the same start."""
@@ -94,7 +112,11 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LPAMD_BENCH_FORCE_SHARDED=1 runs the multi-rank code path (RCCL collectives included)
+    # even for a world of one, to rehearse it on a one-GPU box.
+    force_sharded = os.environ.get("LPAMD_BENCH_FORCE_SHARDED", "0") == "1"
+    use_dist = world > 1 or (force_sharded and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -106,11 +128,11 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not force_sharded:
         eng = lp.TableauEngine(m, N)
         eng.fill_synthetic(n, args.seed)
         run = lambda k: eng.run_pivots(strat, k)
@@ -131,7 +153,7 @@ def main():
     sync_all()
     el = time.perf_counter() - t0
     assert done == K and res == lp.LIMIT, "timed region ended early: result %d after %d pivots" % (res, done)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -144,7 +166,7 @@ def main():
     avg_ms = upd_ms / max(launches, 1)
     algo_bytes = 16.0 * m * active          # every entry of an active local column is read once and written once
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([achieved], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)   # report the slowest rank's kernel rate
         achieved = float(t.item())
@@ -167,7 +189,7 @@ def main():
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, world),
                      "kernel": "k_update", "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
                      "algorithmic_bytes_per_launch": algo_bytes, "active_columns": int(active)},
     }
@@ -178,7 +200,7 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "pivots/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -145,6 +145,20 @@ int lpamd_export_column(lpamd_engine* eng, int64_t e, void* xbuf_dev);
  *    broadcast column (or the given row for MAX_REDUCTION), then the rank-1
  *    update of its shard and RHS replica (asynchronous). */
 int lpamd_apply_pivot(lpamd_engine* eng, int32_t strategy, int64_t e, int64_t r, const void* xbuf_dev);
+/* Host-free variant of steps 2 and 3, for a loop that never waits for the host:
+ * 2'. every rank folds the gathered records on the device (same rule as
+ *     lpamd_fold_candidates) and keeps the winner; a terminal outcome is left in
+ *     the engine's status (asynchronous).
+ * 3'. every rank fills the exchange buffer with the winning column if it owns it,
+ *     with zeros otherwise (asynchronous); the caller then sum-all-reduces the
+ *     buffers as 64-bit integers, which hands every rank the exact column, and
+ *     calls lpamd_apply_pivot with e = r = -1 (they are read on the device). */
+int lpamd_select_candidate_device(lpamd_engine* eng, int32_t strategy, const void* cands_dev, int32_t world);
+int lpamd_export_column_or_zero(lpamd_engine* eng, void* xbuf_dev);
+/* Budget for the multi-GPU loop: after max_pivots more pivots the device steps turn
+ * into no-ops and lpamd_poll reports LPAMD_LIMIT... while running it reports
+ * LPAMD_LIMIT as well; use lpamd_pivot_count to tell how far the loop got. */
+int lpamd_set_pivot_budget(lpamd_engine* eng, int64_t max_pivots);
 /* terminal status after step 4 (synchronises): LPAMD_LIMIT = still running */
 int lpamd_poll(lpamd_engine* eng, int32_t* result);
 

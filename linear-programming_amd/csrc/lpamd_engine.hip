@@ -78,6 +78,7 @@ struct lpamd_engine {
   double* part_v = nullptr;     // [2 * kMaxPartials]: pricing partials, then ratio partials
   int64_t* part_i = nullptr;
   int32_t n_price_part = 1, n_ratio_part = 1, n_row_blocks = 1;
+  int64_t apply_since_pull = 0;        // pivots enqueued since the host last read the device state
   bool price_partials_fresh = false;   // part_v/part_i[0..n_price_part) describe the current objective row and basis
   PivotState* st = nullptr;
   int64_t* trace = nullptr;
@@ -128,6 +129,7 @@ int ensure_trace(lpamd_engine* e, int64_t need) {
 }
 
 int pull_state(lpamd_engine* e) {
+  e->apply_since_pull = 0;
   HIP_TRY(hipMemcpyAsync(&e->h_st, e->st, sizeof(PivotState), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
   return LPAMD_OK;
@@ -850,6 +852,32 @@ int lpamd_select_candidate(lpamd_engine* e, int32_t strategy, const void* cands_
   return LPAMD_OK;
 }
 
+int lpamd_select_candidate_device(lpamd_engine* e, int32_t strategy, const void* cands_dev, int32_t world) {
+  CHECK_LOADED(e);
+  if (!cands_dev || world != e->sh.world) return set_err(LPAMD_E_ARG, "select_candidate_device: bad arguments");
+  if (strategy != LPAMD_MAX_COST && strategy != LPAMD_MAX_REDUCTION)
+    return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+  hipLaunchKernelGGL(k_fold_candidates, dim3(1), dim3(kWave), 0, e->stream, (const Candidate*)cands_dev, (int)world,
+                     strategy == LPAMD_MAX_REDUCTION ? 1 : 0, e->st, e->cand);
+  return check_launch("k_fold_candidates");
+}
+
+int lpamd_export_column_or_zero(lpamd_engine* e, void* xbuf_dev) {
+  CHECK_LOADED(e);
+  if (!xbuf_dev) return set_err(LPAMD_E_ARG, "export_column_or_zero: null exchange buffer");
+  hipLaunchKernelGGL(k_export_or_zero, dim3((unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->sh, e->st, e->cand,
+                     (double*)xbuf_dev);
+  return check_launch("k_export_or_zero");
+}
+
+int lpamd_set_pivot_budget(lpamd_engine* e, int64_t max_pivots) {
+  CHECK_LOADED(e);
+  LP_TRY(pull_state(e));
+  e->h_st.status = ST_RUNNING;
+  e->h_st.max_iter = max_pivots < 0 ? std::numeric_limits<int64_t>::max() : e->h_st.iter + max_pivots;
+  return push_state(e);
+}
+
 int lpamd_export_column(lpamd_engine* e, int64_t col, void* xbuf_dev) {
   CHECK_LOADED(e);
   if (!xbuf_dev || col < 0 || col > e->sh.N + 1 || col == e->sh.N) return set_err(LPAMD_E_ARG, "export_column: bad arguments");
@@ -863,7 +891,10 @@ int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r,
   (void)col;
   (void)r;
   if (!xbuf_dev) return set_err(LPAMD_E_ARG, "apply_pivot: null exchange buffer");
-  LP_TRY(ensure_trace(e, e->h_st.iter + 2));   // h_st was refreshed by lpamd_select_candidate
+  // h_st.iter is refreshed by lpamd_select_candidate / lpamd_poll; between two polls the caller
+  // may enqueue many pivots, so keep generous head-room (the trace stops recording when full).
+  e->apply_since_pull++;
+  LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
   return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, (const double*)xbuf_dev, -1);
 }
 

@@ -461,6 +461,49 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   }
 }
 
+// ------------------------------------------------- multi-GPU exchange helpers
+// Every rank folds the all-gathered candidate records identically (same rule as
+// lpamd_fold_candidates on the host) and keeps the winner in its own `cand`, so
+// no rank has to wait for the host to learn the entering column.
+__global__ __launch_bounds__(kWave) void k_fold_candidates(
+    const Candidate* __restrict__ recs, int world, int strategy_max_reduction, PivotState* __restrict__ st,
+    Candidate* __restrict__ cand) {
+  if (st->status != ST_RUNNING) return;
+  if (threadIdx.x != 0) return;
+  if (st->iter >= st->max_iter) { st->status = ST_LIMIT; return; }
+  Candidate best;
+  best.key = -DBL_MAX; best.gcol = -1; best.row = -1; best.ce = 0.0;
+  bool any = false;
+  for (int k = 0; k < world; k++) {
+    const Candidate c = recs[k];
+    if (c.gcol < 0) continue;
+    any = true;
+    if (strategy_max_reduction && c.row < 0) continue;
+    if (best.gcol < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) best = c;
+  }
+  if (best.gcol < 0) { st->status = any ? ST_UNBOUNDED : ST_SOLVED; return; }
+  *cand = best;
+}
+
+// The owner of the winning column writes it into the exchange buffer, every other
+// rank writes zeros: an integer sum-all-reduce of the buffers (bit patterns added
+// to zeros) then delivers the exact column to every rank without a data-dependent
+// broadcast root.
+__global__ __launch_bounds__(256) void k_export_or_zero(
+    const double* __restrict__ T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand,
+    double* __restrict__ xbuf) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t e = cand->gcol;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sh.lda) return;
+  double v = 0.0;
+  if (e >= 0) {
+    const int64_t eo = ordinal_of(e, sh.N);
+    if (eo % sh.world == sh.rank) v = T[(eo / sh.world) * sh.lda + i];
+  }
+  xbuf[i] = v;
+}
+
 // --------------------------------------------------------------- utilities
 __global__ void k_gather_row(const double* __restrict__ T, int64_t lda, int32_t ncl, int64_t r, double* __restrict__ out) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;

@@ -70,6 +70,9 @@ def library():
         "lpamd_select_candidate": (ctypes.c_int, [vp, i32, vp, i32, P(i64), P(i64), P(i32), P(i32)]),
         "lpamd_fold_candidates": (ctypes.c_int, [i32, vp, i32, i64, P(i64), P(i64), P(i32), P(i32), vp]),
         "lpamd_export_column": (ctypes.c_int, [vp, i64, vp]),
+        "lpamd_select_candidate_device": (ctypes.c_int, [vp, i32, vp, i32]),
+        "lpamd_export_column_or_zero": (ctypes.c_int, [vp, vp]),
+        "lpamd_set_pivot_budget": (ctypes.c_int, [vp, i64]),
         "lpamd_apply_pivot": (ctypes.c_int, [vp, i32, i64, i64, vp]),
         "lpamd_poll": (ctypes.c_int, [vp, P(i32)]),
     }
@@ -237,6 +240,15 @@ class TableauEngine:
         _ck(self.L.lpamd_select_candidate(self.h, int(strategy), ctypes.c_void_p(cands_ptr), self.world,
                                           ctypes.byref(e), ctypes.byref(r), ctypes.byref(owner), ctypes.byref(res)))
         return e.value, r.value, owner.value, res.value
+
+    def select_candidate_device(self, strategy, cands_ptr):
+        _ck(self.L.lpamd_select_candidate_device(self.h, int(strategy), ctypes.c_void_p(cands_ptr), self.world))
+
+    def export_column_or_zero(self, xbuf_ptr):
+        _ck(self.L.lpamd_export_column_or_zero(self.h, ctypes.c_void_p(xbuf_ptr)))
+
+    def set_pivot_budget(self, max_pivots):
+        _ck(self.L.lpamd_set_pivot_budget(self.h, int(max_pivots)))
 
     def export_column(self, e, xbuf_ptr):
         _ck(self.L.lpamd_export_column(self.h, int(e), ctypes.c_void_p(xbuf_ptr)))

@@ -44,6 +44,7 @@ class HostShard:
         self.status = eng.LIMIT                 # LIMIT = still running
         self.winner = None
         self.trace = []
+        self.budget_end = None
 
     # ---- interface of EngineShard ----
     def exchange_doubles(self):
@@ -96,11 +97,43 @@ class HostShard:
             self.status = res
         return e, r, owner, res
 
+    def select_candidate_device(self, strategy, cands):
+        if self.status != eng.LIMIT:
+            return
+        if self.budget_end is not None and len(self.trace) >= self.budget_end:
+            self.winner = None
+            return
+        e, r, owner, res, win = eng.fold_candidates(strategy, cands.numpy(), self.world, self.N)
+        self.winner = win if res == eng.LIMIT else None
+        if res != eng.LIMIT:
+            self.status = res
+
+    def export_column_or_zero(self, xbuf):
+        x = xbuf.numpy()
+        x[:] = 0.0
+        if self.status != eng.LIMIT or self.winner is None:
+            return
+        e = int(self.winner.view(np.int64)[1])
+        hit = np.nonzero(self.gcols == e)[0]
+        if len(hit):
+            x[: self.m] = self.T[:, int(hit[0])]
+
+    def set_pivot_budget(self, k):
+        self.budget_end = None if k < 0 else len(self.trace) + k
+
+    def pivot_count(self):
+        return len(self.trace)
+
     def export_column(self, e, xbuf):
         l = int(np.nonzero(self.gcols == e)[0][0])
         xbuf.numpy()[: self.m] = self.T[:, l]
 
     def apply_pivot(self, strategy, e, r, xbuf):
+        if self.status != eng.LIMIT or self.winner is None:
+            return
+        if e < 0:                                # host-free exchange: take (e, r) from the folded winner
+            e = int(self.winner.view(np.int64)[1])
+            r = int(self.winner.view(np.int64)[2])
         col = np.array(xbuf.numpy()[: self.m], dtype=np.float64)
         if strategy == eng.MAX_COST:
             rows = np.nonzero(f32(col) <= np.float32(-1e-6))[0]

@@ -44,6 +44,36 @@ def run_loopback(shards, strategy, eng, max_pivots=-1):
     return shards[0].poll(), trace
 
 
+def run_loopback_hostfree(shards, strategy, eng, poll_every=16):
+    """The host-free exchange: device fold of the gathered records, export-or-zero,
+    integer sum of the per-rank buffers (what the sum-all-reduce computes)."""
+    world = len(shards)
+    cand = [s.new_buffer(4) for s in shards]
+    cands = shards[0].new_buffer(4 * world)
+    xbufs = [s.new_buffer(s.exchange_doubles()) for s in shards]
+    for s in shards:
+        s.set_pivot_budget(-1)
+    while True:
+        for _ in range(poll_every):
+            for s, c in zip(shards, cand):
+                s.local_candidate(strategy, c)
+            for k, c in enumerate(cand):
+                cands[4 * k: 4 * k + 4].copy_(c)
+            for s, x in zip(shards, xbufs):
+                s.select_candidate_device(strategy, cands)
+                s.export_column_or_zero(x)
+            total = xbufs[0].view(torch.int64).clone()
+            for x in xbufs[1:]:
+                total += x.view(torch.int64)
+            for s, x in zip(shards, xbufs):
+                x.view(torch.int64).copy_(total)
+                s.apply_pivot(strategy, -1, -1, x)
+        res = [s.poll() for s in shards]
+        assert all(r == res[0] for r in res)
+        if res[0] != eng.LIMIT:
+            return res[0]
+
+
 def assemble(shards, m, N):
     T = np.zeros((m, N + 2), order="F")
     obj = np.zeros(N + 2)
@@ -56,9 +86,10 @@ def assemble(shards, m, N):
     return T, obj, basic, rhs
 
 
+@pytest.mark.parametrize("hostfree", [False, True])
 @pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
 @pytest.mark.parametrize("world", [2, 3])
-def test_two_shards_one_gpu_synthetic(lpamd, strategy, world):
+def test_two_shards_one_gpu_synthetic(lpamd, strategy, world, hostfree):
     sharded = importlib.import_module("linear-programming_amd.sharded")
     eng = importlib.import_module("linear-programming_amd.engine")
     torch.cuda.set_device(0)
@@ -70,10 +101,14 @@ def test_two_shards_one_gpu_synthetic(lpamd, strategy, world):
         s.eng.fill_synthetic(n, seed)
     dt = lo.DenseTableau.synthetic(m, n, seed)
     with torch.cuda.stream(stream):
-        res, trace = run_loopback(shards, eng.STRATEGY[strategy], eng)
+        if hostfree:
+            res = run_loopback_hostfree(shards, eng.STRATEGY[strategy], eng)
+        else:
+            res, trace = run_loopback(shards, eng.STRATEGY[strategy], eng)
     torch.cuda.synchronize()
     assert res == dt.solve(lo.STRATEGY[strategy]) == eng.SOLVED
-    assert trace == [e for e, _ in dt.trace()]
+    if not hostfree:
+        assert trace == [e for e, _ in dt.trace()]
     for s in shards:                      # every rank recorded the full (e, r) trace
         assert s.eng.trace() == dt.trace()
     T, obj, basic, rhs = assemble(shards, m, n + m)
@@ -130,7 +165,8 @@ def test_phase1_is_rejected_on_shards(lpamd):
         e.solve(eng.MAX_COST)
 
 
-def test_rccl_collectives_single_rank(lpamd):
+@pytest.mark.parametrize("exchange", ["allreduce", "broadcast"])
+def test_rccl_collectives_single_rank(lpamd, exchange):
     """World of one over the nccl (= RCCL) backend: the all-gather and the broadcast
     of the sharded loop run for real on the GPU."""
     import socket
@@ -148,7 +184,7 @@ def test_rccl_collectives_single_rank(lpamd):
         m, n, seed = 300, 500, 9
         shard = sharded.EngineShard(m, n + m, 0, 1, dev)
         shard.eng.fill_synthetic(n, seed)
-        solver = sharded.ShardedSolver(shard)
+        solver = sharded.ShardedSolver(shard, exchange=exchange, poll_every=5)
         assert solver.use_dist
         res, done = solver.run_pivots(eng.MAX_REDUCTION, 12)
         res2, done2 = solver.run_pivots(eng.MAX_COST, -1)
