@@ -155,9 +155,10 @@ int lpamd_apply_pivot(lpamd_engine* eng, int32_t strategy, int64_t e, int64_t r,
  *     calls lpamd_apply_pivot with e = r = -1 (they are read on the device). */
 int lpamd_select_candidate_device(lpamd_engine* eng, int32_t strategy, const void* cands_dev, int32_t world);
 int lpamd_export_column_or_zero(lpamd_engine* eng, void* xbuf_dev);
-/* Budget for the multi-GPU loop: after max_pivots more pivots the device steps turn
- * into no-ops and lpamd_poll reports LPAMD_LIMIT... while running it reports
- * LPAMD_LIMIT as well; use lpamd_pivot_count to tell how far the loop got. */
+/* Pivot budget of the step-wise loop: after max_pivots more pivots (< 0: no limit)
+ * the device steps turn into no-ops.  Also re-arms a loop that hit its budget.
+ * lpamd_poll reports LPAMD_LIMIT both while running and when the budget is
+ * spent; lpamd_pivot_count tells how far the loop got.  Synchronises. */
 int lpamd_set_pivot_budget(lpamd_engine* eng, int64_t max_pivots);
 /* terminal status after step 4 (synchronises): LPAMD_LIMIT = still running */
 int lpamd_poll(lpamd_engine* eng, int32_t* result);
