@@ -169,8 +169,13 @@ int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
     hipLaunchKernelGGL(k_pr_columns, dim3(e->sh.nloc), dim3(256), 0, e->stream, e->T, e->obj, e->is_basic, e->sh, e->st,
                        e->cmin, e->crow);
     LP_TRY(check_launch("k_pr_columns"));
-    hipLaunchKernelGGL(k_pr_select, dim3(1), dim3(kSelectThreads), 0, e->stream, e->obj, e->cmin, e->crow, e->sh, e->st, out);
-    return check_launch("k_pr_select");
+    hipLaunchKernelGGL(k_pr_partial, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->obj, e->cmin, e->crow, e->sh, e->st,
+                       e->part_v, e->part_i, e->part_i + 2 * kMaxPartials);
+    LP_TRY(check_launch("k_pr_partial"));
+    e->price_partials_fresh = false;   // the partial buffers now hold max-reduction scores
+    hipLaunchKernelGGL(k_pr_fold, dim3(1), dim3(kPartialThreads), 0, e->stream, e->obj, e->crow, e->part_v, e->part_i,
+                       e->part_i + 2 * kMaxPartials, e->n_price_part, e->sh, e->st, out);
+    return check_launch("k_pr_fold");
   }
   // reference: neither branch of lp_simplex_tableau.cc:188/235 fires and the live
   // assert at :14 aborts; here the call is rejected instead.
@@ -385,7 +390,7 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
-  HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 2 * kMaxPartials));
+  HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 3 * kMaxPartials));
   // partial reductions: about 2048 columns / 1024 rows per workgroup, at most kMaxPartials workgroups
   e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 1 + kPartialThreads - 1) / kPartialThreads));
   e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));

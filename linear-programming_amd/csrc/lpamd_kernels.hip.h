@@ -172,6 +172,19 @@ __global__ __launch_bounds__(kPartialThreads) void k_price_fold(
 // and 341-352): one workgroup per candidate column computes the minimum ratio
 // b_i / (-T_ij) over rows with (float)T_ij <= -1e-6f, lowest row on ties.
 // crow[l] = -2: not a candidate, -1: candidate without eligible row.
+// The pass is a read-only stream over the candidate columns (8*m bytes each, 16 B
+// per lane, four loads in flight); the RHS replica comes from L2.  The correctly
+// rounded division is only executed for entries that can still beat the lane's
+// running minimum: for best > 0, b > best * (-a) * (1 + 2^-40) proves b / (-a) > best
+// for any rounding of the products and the quotient, so skipping those entries is exact.
+__device__ __forceinline__ void pr_consider(double a, double b, int64_t i, double& bv, int64_t& bi) {
+  if ((float)a > -1e-6f) return;                 // _IsNonNegative (padding rows hold 0 and drop out here too)
+  const double na = -a;
+  if (bv > 0.0 && b > __dmul_rn(__dmul_rn(bv, na), 1.0000000000009095)) return;
+  const double ratio = b / na;
+  if (bv > ratio) { bv = ratio; bi = i; }
+}
+
 __global__ __launch_bounds__(256) void k_pr_columns(
     const double* __restrict__ T, const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
     Shape sh, const PivotState* __restrict__ st, double* __restrict__ cmin, int64_t* __restrict__ crow) {
@@ -183,15 +196,27 @@ __global__ __launch_bounds__(256) void k_pr_columns(
     if (threadIdx.x == 0) crow[l] = -2;
     return;
   }
-  const double* __restrict__ col = T + (int64_t)l * sh.lda;
-  const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+  const double2* __restrict__ col = reinterpret_cast<const double2*>(T + (int64_t)l * sh.lda);
+  const double2* __restrict__ rhs = reinterpret_cast<const double2*>(T + (int64_t)sh.nloc * sh.lda);
+  const int n_vec = (int)(sh.lda / 2);           // multiple of 256
   double bv = DBL_MAX;
   int64_t bi = -1;
-  for (int64_t i = threadIdx.x; i < sh.m; i += 256) {
-    const double a = col[i];
-    if ((float)a > -1e-6f) continue;          // _IsNonNegative
-    const double ratio = rhs[i] / (-a);
-    if (bv > ratio) { bv = ratio; bi = i; }
+  int v = threadIdx.x;
+  for (; v + 3 * 256 < n_vec; v += 4 * 256) {
+    double2 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { a[u] = col[v + u * 256]; b[u] = rhs[v + u * 256]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int64_t i = 2 * (int64_t)(v + u * 256);
+      pr_consider(a[u].x, b[u].x, i, bv, bi);
+      pr_consider(a[u].y, b[u].y, i + 1, bv, bi);
+    }
+  }
+  for (; v < n_vec; v += 256) {
+    const double2 a = col[v], b = rhs[v];
+    pr_consider(a.x, b.x, 2 * (int64_t)v, bv, bi);
+    pr_consider(a.y, b.y, 2 * (int64_t)v + 1, bv, bi);
   }
   block_arg<false, 256>(bv, bi, s_v, s_i);
   if (threadIdx.x == 0) { cmin[l] = bv; crow[l] = bi; }
@@ -200,16 +225,18 @@ __global__ __launch_bounds__(256) void k_pr_columns(
 // MAX_REDUCTION pricing, fold over columns (reference lp_simplex_tableau.cc:310-325
 // and 353-362): largest c_j * min_j over candidates that have a row, lowest
 // column on ties; if no candidate has a row the first candidate is reported
-// with row = -1 (=> unbounded).
-__global__ __launch_bounds__(kSelectThreads) void k_pr_select(
+// with row = -1 (=> unbounded).  Stage 1: per-workgroup partials (best score and
+// first candidate); stage 2 (k_pr_fold): one workgroup folds them into the record.
+__global__ __launch_bounds__(kPartialThreads) void k_pr_partial(
     const double* __restrict__ obj, const double* __restrict__ cmin, const int64_t* __restrict__ crow,
-    Shape sh, PivotState* __restrict__ st, Candidate* __restrict__ cand) {
-  __shared__ double s_v[kSelectThreads / kWave];
-  __shared__ int64_t s_i[kSelectThreads / kWave];
+    Shape sh, const PivotState* __restrict__ st, double* __restrict__ pv, int64_t* __restrict__ pi,
+    int64_t* __restrict__ pfirst) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   double bv = -DBL_MAX, fv = 0.0;
   int64_t bi = -1, fi = -1;
-  for (int l = threadIdx.x; l < sh.nloc; l += kSelectThreads) {
+  for (int l = blockIdx.x * kPartialThreads + threadIdx.x; l < sh.nloc; l += gridDim.x * kPartialThreads) {
     const int64_t cr = crow[l];
     if (cr == -2) continue;
     if (fi < 0) fi = l;
@@ -217,13 +244,32 @@ __global__ __launch_bounds__(kSelectThreads) void k_pr_select(
     const double score = __dmul_rn(obj[l], cmin[l]);
     if (score > bv) { bv = score; bi = l; }
   }
-  block_arg<true, kSelectThreads>(bv, bi, s_v, s_i);
+  block_arg<true, kPartialThreads>(bv, bi, s_v, s_i);
+  fv = fi < 0 ? 0.0 : -(double)fi;   // first candidate = smallest local index: arg-max of -index
+  block_arg<true, kPartialThreads>(fv, fi, s_v, s_i);
+  if (threadIdx.x == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; pfirst[blockIdx.x] = fi; }
+}
+
+__global__ __launch_bounds__(kPartialThreads) void k_pr_fold(
+    const double* __restrict__ obj, const int64_t* __restrict__ crow,
+    const double* __restrict__ pv, const int64_t* __restrict__ pi, const int64_t* __restrict__ pfirst, int n_part,
+    Shape sh, PivotState* __restrict__ st, Candidate* __restrict__ cand) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
   if (st->iter >= st->max_iter) { if (threadIdx.x == 0) st->status = ST_LIMIT; return; }
-  if (threadIdx.x == 0) st->n_active = 0;
-  // first candidate = smallest local index: reduce with key = -index
-  fv = fi < 0 ? 0.0 : -(double)fi;
-  block_arg<true, kSelectThreads>(fv, fi, s_v, s_i);
+  double bv;
+  int64_t bi;
+  fold_partials<true, kPartialThreads>(pv, pi, n_part, bv, bi, s_v, s_i);
+  double fv = 0.0;
+  int64_t fi = -1;
+  for (int k = threadIdx.x; k < n_part; k += kPartialThreads) {
+    const int64_t f = pfirst[k];
+    if (f >= 0) take_max(fv, fi, -(double)f, f);
+  }
+  block_arg<true, kPartialThreads>(fv, fi, s_v, s_i);
   if (threadIdx.x == 0) {
+    st->n_active = 0;
     Candidate c;
     if (bi >= 0) {
       c.key = bv; c.gcol = gcol_of(bi * sh.world + sh.rank, sh.N); c.row = crow[bi]; c.ce = obj[bi];
