@@ -66,7 +66,6 @@ struct lpamd_engine {
   // device memory
   double* T = nullptr;
   double* obj = nullptr;
-  double* obj_saved = nullptr;
   uint8_t* is_basic = nullptr;
   int64_t* basis = nullptr;
   double* colp = nullptr;
@@ -337,6 +336,8 @@ const char* lpamd_last_error(void) { return g_err; }
 const char* lpamd_version(void) { return "lpamd 0.1 (gfx950)"; }
 int64_t lpamd_exchange_bytes(int64_t m) { return round_up(std::max<int64_t>(m, 1), kSlabRows) * (int64_t)sizeof(double); }
 
+static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int32_t rank, int32_t world, void* hip_stream);
+
 int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t world, void* hip_stream) {
   if (!out) return set_err(LPAMD_E_ARG, "out is null");
   *out = nullptr;
@@ -349,6 +350,19 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
   lpamd_engine* e = new lpamd_engine();
+  const int rc = create_impl(e, m, N, nloc, rank, world, hip_stream);
+  if (rc != LPAMD_OK) {
+    char keep[sizeof(g_err)];
+    std::memcpy(keep, g_err, sizeof(keep));   // lpamd_destroy must not clobber the cause
+    lpamd_destroy(e);
+    std::memcpy(g_err, keep, sizeof(keep));
+    return rc;
+  }
+  *out = e;
+  return LPAMD_OK;
+}
+
+static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int32_t rank, int32_t world, void* hip_stream) {
   HIP_TRY(hipGetDevice(&e->device));
   e->sh.m = m;
   e->sh.N = N;
@@ -375,12 +389,9 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   }
   const size_t tbytes = sizeof(double) * (size_t)e->sh.lda * (size_t)e->ncl;
   hipError_t err = hipMalloc(&e->T, tbytes);
-  if (err != hipSuccess) {
-    delete e;
+  if (err != hipSuccess)
     return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB for the tableau shard failed: %s", tbytes / 1e9, hipGetErrorString(err));
-  }
   HIP_TRY(hipMalloc(&e->obj, sizeof(double) * e->ncl));
-  HIP_TRY(hipMalloc(&e->obj_saved, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->is_basic, e->ncl));
   HIP_TRY(hipMalloc(&e->basis, sizeof(int64_t) * m));
   HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda));
@@ -391,7 +402,7 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
   HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 3 * kMaxPartials));
-  // partial reductions: about 2048 columns / 1024 rows per workgroup, at most kMaxPartials workgroups
+  // partial reductions: 256 columns / 256 rows per workgroup, strided beyond kMaxPartials workgroups
   e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 1 + kPartialThreads - 1) / kPartialThreads));
   e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
   e->n_row_blocks = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
@@ -401,19 +412,18 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   std::memset(&e->h_st, 0, sizeof(PivotState));
   LP_TRY(ensure_trace(e, 4096));
   HIP_TRY(hipStreamSynchronize(e->stream));
-  *out = e;
   return LPAMD_OK;
 }
 
 int lpamd_destroy(lpamd_engine* e) {
   if (!e) return LPAMD_OK;
-  hipSetDevice(e->device);
-  hipStreamSynchronize(e->stream);
-  for (hipEvent_t ev : e->ev) hipEventDestroy(ev);
-  void* ptrs[] = {e->T, e->obj, e->obj_saved, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->cand, e->part_v, e->part_i, e->st, e->trace};
+  (void)hipSetDevice(e->device);
+  if (e->stream) (void)hipStreamSynchronize(e->stream);
+  for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+  void* ptrs[] = {e->T, e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->cand, e->part_v, e->part_i, e->st, e->trace};
   for (void* p : ptrs)
-    if (p) hipFree(p);
-  if (e->own_stream) hipStreamDestroy(e->stream);
+    if (p) (void)hipFree(p);
+  if (e->own_stream) (void)hipStreamDestroy(e->stream);
   delete e;
   return LPAMD_OK;
 }
@@ -454,7 +464,7 @@ int lpamd_fill_synthetic(lpamd_engine* e, int64_t n_struct, uint64_t seed) {
   const Shape& sh = e->sh;
   if (n_struct <= 0 || n_struct + sh.m != sh.N)
     return set_err(LPAMD_E_ARG, "synthetic LP needs N == n_struct + m (N=%lld n=%lld m=%lld)", (long long)sh.N, (long long)n_struct, (long long)sh.m);
-  hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)((sh.lda + 255) / 256), (unsigned)e->ncl), dim3(256), 0, e->stream, e->T, e->obj,
+  hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)e->ncl, (unsigned)((sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->obj,
                      e->is_basic, e->basis, sh, n_struct, seed);
   LP_TRY(check_launch("k_fill_synthetic"));
   reset_state(e);

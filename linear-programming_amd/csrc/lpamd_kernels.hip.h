@@ -608,9 +608,9 @@ __host__ __device__ __forceinline__ double synth_entry(uint64_t seed, int64_t m,
 __global__ __launch_bounds__(256) void k_fill_synthetic(
     double* __restrict__ T, double* __restrict__ obj, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
     Shape sh, int64_t n, uint64_t seed) {
-  const int l = blockIdx.y;                       // local column, nloc = RHS replica
+  const int l = blockIdx.x;                       // local column, nloc = RHS replica
   const int64_t g = l < sh.nloc ? gcol_of((int64_t)l * sh.world + sh.rank, sh.N) : sh.N;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (i < sh.lda) T[(int64_t)l * sh.lda + i] = i < sh.m ? synth_entry(seed, sh.m, n, i, g) : 0.0;
   if (i == 0) {
     obj[l] = synth_entry(seed, sh.m, n, sh.m, g);
