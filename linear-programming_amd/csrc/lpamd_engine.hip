@@ -367,6 +367,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->sh.m = m;
   e->sh.N = N;
   e->sh.lda = round_up(m, kSlabRows);
+  if (const char* env = getenv("LPAMD_LDA_PAD")) e->sh.lda += round_up(std::max(0, atoi(env)), kSlabRows);
   e->sh.nloc = (int32_t)nloc;
   e->sh.rank = rank;
   e->sh.world = world;

@@ -95,6 +95,9 @@ class ShardedSolver:
         self.cands = shard.new_buffer(4 * self.world)
         self.xbuf = shard.new_buffer(shard.exchange_doubles())
         self.xbuf_words = self.xbuf.view(torch.int64)
+        if self.xbuf.is_cuda:
+            # the zero-fills above ran on the allocating stream; the loop uses the shard's own stream
+            torch.cuda.synchronize(self.xbuf.device)
 
     def run_pivots(self, strategy, k):
         """At most k pivots (k < 0: until termination).  Returns (Result, pivots done)."""

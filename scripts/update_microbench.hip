@@ -106,6 +106,47 @@ __global__ __launch_bounds__(BS) void k_fullcol2(double* __restrict__ T, long ld
   }
 }
 
+// V4: linear sweep.  Work item = (column, batch of UNR*BS vectors); items are dealt round-robin so the
+// resident workgroups always cover one contiguous window of memory.  All loads of a batch before its stores.
+template <int BS, int UNR, bool NT>
+__global__ __launch_bounds__(BS, 2) void k_linear(double* __restrict__ T, long lda, int n_vec, int ncols,
+                                                   const double* __restrict__ colp, const double* __restrict__ rowp) {
+  const int per_col = n_vec / (UNR * BS);
+  const long n_items = (long)ncols * per_col;
+  const double2* cp = reinterpret_cast<const double2*>(colp);
+  for (long it = blockIdx.x; it < n_items; it += gridDim.x) {
+    const int k = (int)(it / per_col), ch = (int)(it % per_col);
+    const double r0 = rowp[k];
+    double2* p = reinterpret_cast<double2*>(T + (long)k * lda) + (long)ch * UNR * BS + threadIdx.x;
+    const double2* c0 = cp + (long)ch * UNR * BS + threadIdx.x;
+    double2 t[UNR], c[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) { t[u] = ld<NT>(p + u * BS); c[u] = c0[u * BS]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < UNR; u++) st<NT>(p + u * BS, apply(t[u], c[u], r0));
+  }
+}
+
+// V5: full columns with all loads of a batch issued before its stores (the engine's kernel)
+template <int BS, int UNR, bool NT>
+__global__ __launch_bounds__(BS, 2) void k_fullcol_batched(double* __restrict__ T, long lda, int n_vec, int ncols,
+                                                            const double* __restrict__ colp, const double* __restrict__ rowp) {
+  const double2* cp = reinterpret_cast<const double2*>(colp);
+  for (int k = blockIdx.x; k < ncols; k += gridDim.x) {
+    const double r0 = rowp[k];
+    double2* p = reinterpret_cast<double2*>(T + (long)k * lda);
+    for (int v = threadIdx.x; v + (UNR - 1) * BS < n_vec; v += UNR * BS) {
+      double2 t[UNR], c[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; u++) { t[u] = ld<NT>(p + v + u * BS); c[u] = cp[v + u * BS]; }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < UNR; u++) st<NT>(p + v + u * BS, apply(t[u], c[u], r0));
+    }
+  }
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void k_copy_nt(const double2* __restrict__ a, double2* __restrict__ b, long n2) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n2; i += (long)gridDim.x * 256) st<NT>(b + i, ld<NT>(a + i));
@@ -156,26 +197,23 @@ int main(int argc, char** argv) {
   for (int g : {2048, 8192})  { char b[64]; snprintf(b, 64, "copy out-of-place grid=%d", g); report(b, time_it([&] { hipLaunchKernelGGL(k_copy, dim3(g), dim3(256), 0, 0, (const double2*)T, (double2*)T2, n2); }, reps)); }
   for (int g : {2048, 8192})  { char b[64]; snprintf(b, 64, "copy nt grid=%d", g); report(b, time_it([&] { hipLaunchKernelGGL(k_copy_nt<true>, dim3(g), dim3(256), 0, 0, (const double2*)T, (double2*)T2, n2); }, reps)); }
   { report("hipMemcpyDtoD", time_it([&] { CK(hipMemcpyAsync(T2, T, bytes, hipMemcpyDeviceToDevice, 0)); }, reps)); }
-#define RUN_F2(BS, UN, NTL, NTS, CONTIG, G) do { char b[112]; snprintf(b, 112, "fullcol2 bs=%d unr=%d ntl=%d nts=%d contig=%d grid=%d", BS, UN, NTL, NTS, CONTIG, G); \
-    report(b, time_it([&] { hipLaunchKernelGGL((k_fullcol2<BS, UN, NTL, NTS, CONTIG>), dim3(G), dim3(BS), 0, 0, T, lda, n_vec, n, colp, rowp); }, reps)); } while (0)
-  RUN_F2(256, 8, true, true, false, 2048);
-  RUN_F2(256, 8, true, false, false, 2048);
-  RUN_F2(256, 8, false, true, false, 2048);
-  RUN_F2(256, 4, true, true, false, 2048);
-  RUN_F2(256, 2, true, true, false, 2048);
-  RUN_F2(256, 16, true, true, false, 2048);
-  RUN_F2(512, 4, true, true, false, 1024);
-  RUN_F2(512, 8, true, true, false, 1024);
-  RUN_F2(1024, 4, true, true, false, 512);
-  RUN_F2(1024, 2, true, true, false, 1024);
-  RUN_F2(256, 8, true, true, false, 512);
-  RUN_F2(256, 8, true, true, false, 1024);
-  RUN_F2(256, 8, true, true, false, 4096);
-  RUN_F2(256, 8, true, true, false, 16384);
-  RUN_F2(256, 8, true, true, true, 2048);
-  RUN_F2(256, 8, true, true, true, 1024);
-  RUN_F2(256, 8, true, true, true, 4096);
-  RUN_F2(64, 8, true, true, false, 8192);
-  RUN_F2(128, 8, true, true, false, 4096);
+#define RUN_V(KERN, BS, UN, NT, G) do { char b[112]; snprintf(b, 112, #KERN " bs=%d unr=%d nt=%d grid=%d", BS, UN, NT, G); \
+    report(b, time_it([&] { hipLaunchKernelGGL((KERN<BS, UN, NT>), dim3(G), dim3(BS), 0, 0, T, lda, n_vec, n, colp, rowp); }, reps)); } while (0)
+  RUN_V(k_fullcol_batched, 256, 16, true, 8192);
+  RUN_V(k_fullcol_batched, 256, 16, true, 768);
+  RUN_V(k_fullcol_batched, 256, 8, true, 8192);
+  RUN_V(k_fullcol_batched, 512, 8, true, 4096);
+  RUN_V(k_fullcol_batched, 512, 16, true, 4096);
+  RUN_V(k_fullcol_batched, 1024, 8, true, 2048);
+  RUN_V(k_linear, 256, 16, true, 768);
+  RUN_V(k_linear, 256, 16, true, 2048);
+  RUN_V(k_linear, 256, 16, true, 8192);
+  RUN_V(k_linear, 256, 16, true, 65536);
+  RUN_V(k_linear, 256, 8, true, 8192);
+  RUN_V(k_linear, 512, 8, true, 4096);
+  RUN_V(k_linear, 512, 16, true, 4096);
+  RUN_V(k_linear, 1024, 8, true, 2048);
+  RUN_V(k_linear, 1024, 16, true, 2048);
+  RUN_V(k_linear, 256, 16, false, 8192);
   return 0;
 }
