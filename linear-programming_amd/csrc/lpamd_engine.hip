@@ -60,6 +60,8 @@ struct lpamd_engine {
   bool update_nt = false;       // nontemporal loads/stores: shards beyond the Infinity Cache
   int32_t update_unroll_cap = 16;
   bool update_prec = true;      // load col' together with the tableau batch
+  bool update_prec_fused = true;
+  bool fuse_pr_enabled = true;  // max-reduction pricing of the next iteration inside the update
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -71,8 +73,11 @@ struct lpamd_engine {
   double* colp = nullptr;
   double* rowp = nullptr;   // also scratch for row gathers / column values
   int32_t* active = nullptr;
-  double* cmin = nullptr;
-  int64_t* crow = nullptr;
+  double* cmin = nullptr;       // max-reduction pricing: per-column minimum ratio ...
+  int64_t* crow = nullptr;      // ... its row (-1 none, -2 not a candidate) ...
+  int64_t* pr_stamp = nullptr;  // ... and the pivot count for which the pair is valid
+  double* rhs_next = nullptr;   // right-hand side after the pivot being applied
+  uint8_t* cand_next = nullptr; // pricing candidates after the pivot being applied
   Candidate* cand = nullptr;
   double* part_v = nullptr;     // [2 * kMaxPartials]: pricing partials, then ratio partials
   int64_t* part_i = nullptr;
@@ -138,6 +143,13 @@ int push_state(lpamd_engine* e) {
   HIP_TRY(hipStreamSynchronize(e->stream));   // h_st may be edited right after
   return LPAMD_OK;
 }
+// cmin/crow entries are trusted when pr_stamp equals the pivot count; anything that
+// changes the tableau outside the update kernel, or rewinds the count, drops them.
+int invalidate_pr(lpamd_engine* e) {
+  HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
+  return LPAMD_OK;
+}
+
 void reset_state(lpamd_engine* e) {
   e->price_partials_fresh = false;
   std::memset(&e->h_st, 0, sizeof(PivotState));
@@ -166,7 +178,7 @@ int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
   }
   if (strategy == LPAMD_MAX_REDUCTION) {
     hipLaunchKernelGGL(k_pr_columns, dim3(e->sh.nloc), dim3(256), 0, e->stream, e->T, e->obj, e->is_basic, e->sh, e->st,
-                       e->cmin, e->crow);
+                       e->cmin, e->crow, e->pr_stamp);
     LP_TRY(check_launch("k_pr_columns"));
     hipLaunchKernelGGL(k_pr_partial, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->obj, e->cmin, e->crow, e->sh, e->st,
                        e->part_v, e->part_i, e->part_i + 2 * kMaxPartials);
@@ -182,18 +194,24 @@ int enqueue_pricing(lpamd_engine* e, int strategy, Candidate* out) {
 }
 
 template <int kUnroll>
-void launch_update(lpamd_engine* e, int grid, bool nt) {
-#define LPAMD_LAUNCH_UPDATE(NT, PC)                                                                                         \
-  hipLaunchKernelGGL((k_update<kUnroll, NT, PC>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, \
-                     e->rowp, e->active, e->st, e->sh, e->is_basic, e->basis)
-  if (nt && e->update_prec) LPAMD_LAUNCH_UPDATE(true, true);
-  else if (nt) LPAMD_LAUNCH_UPDATE(true, false);
-  else if (e->update_prec) LPAMD_LAUNCH_UPDATE(false, true);
-  else LPAMD_LAUNCH_UPDATE(false, false);
+void launch_update(lpamd_engine* e, int grid, bool nt, bool fuse_pr) {
+#define LPAMD_LAUNCH_UPDATE(NT, PC, PR)                                                                                         \
+  hipLaunchKernelGGL((k_update<kUnroll, NT, PC, PR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, \
+                     e->rowp, e->active, e->st, e->sh, e->is_basic, e->basis, e->rhs_next, e->cand_next, e->cmin, e->crow,      \
+                     e->pr_stamp)
+  if (fuse_pr) {   // max-reduction pricing of the next iteration rides along
+    if (nt && e->update_prec_fused) LPAMD_LAUNCH_UPDATE(true, true, true);
+    else if (nt) LPAMD_LAUNCH_UPDATE(true, false, true);
+    else if (e->update_prec_fused) LPAMD_LAUNCH_UPDATE(false, true, true);
+    else LPAMD_LAUNCH_UPDATE(false, false, true);
+  } else if (nt && e->update_prec) LPAMD_LAUNCH_UPDATE(true, true, false);
+  else if (nt) LPAMD_LAUNCH_UPDATE(true, false, false);
+  else if (e->update_prec) LPAMD_LAUNCH_UPDATE(false, true, false);
+  else LPAMD_LAUNCH_UPDATE(false, false, false);
 #undef LPAMD_LAUNCH_UPDATE
 }
 
-int enqueue_update(lpamd_engine* e) {
+int enqueue_update(lpamd_engine* e, bool fuse_pr) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->ev_used + 2 > e->ev.size()) {
@@ -210,12 +228,12 @@ int enqueue_update(lpamd_engine* e) {
   // accesses in flight per lane: as many as one column allows, at most 16
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);   // 512-row slabs = 256 vectors of 16 B
   const int grid = e->update_grid;
-  if (n_slabs >= 32) launch_update<32>(e, grid, e->update_nt);
-  else if (n_slabs >= 16) launch_update<16>(e, grid, e->update_nt);
-  else if (n_slabs >= 8) launch_update<8>(e, grid, e->update_nt);
-  else if (n_slabs >= 4) launch_update<4>(e, grid, e->update_nt);
-  else if (n_slabs >= 2) launch_update<2>(e, grid, e->update_nt);
-  else launch_update<1>(e, grid, e->update_nt);
+  if (n_slabs >= 32) launch_update<32>(e, grid, e->update_nt, fuse_pr);
+  else if (n_slabs >= 16) launch_update<16>(e, grid, e->update_nt, fuse_pr);
+  else if (n_slabs >= 8) launch_update<8>(e, grid, e->update_nt, fuse_pr);
+  else if (n_slabs >= 4) launch_update<4>(e, grid, e->update_nt, fuse_pr);
+  else if (n_slabs >= 2) launch_update<2>(e, grid, e->update_nt, fuse_pr);
+  else launch_update<1>(e, grid, e->update_nt, fuse_pr);
   LP_TRY(check_launch("k_update"));
   if (e->profiling) HIP_TRY(hipEventRecord(e1, e->stream));
   return LPAMD_OK;
@@ -234,27 +252,28 @@ int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, con
 }
 
 // pivot set-up + row gather (one launch), then the rank-1 update
-int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override) {
+int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override,
+                            bool fuse_pr = false) {
   const double* rv = e->part_v + kMaxPartials;
   const int64_t* ri = e->part_i + kMaxPartials;
   const int grid = e->n_row_blocks + e->n_price_part;   // column workgroups double as the next pricing partials
   if (find_row)
     hipLaunchKernelGGL(k_pivot_finalize<true>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
                        e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
-                       e->trace, e->trace_cap, e->part_v, e->part_i);
+                       e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next);
   else
     hipLaunchKernelGGL(k_pivot_finalize<false>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
                        e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
-                       e->trace, e->trace_cap, e->part_v, e->part_i);
+                       e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next);
   LP_TRY(check_launch("k_pivot_finalize"));
   e->price_partials_fresh = true;
-  return enqueue_update(e);
+  return enqueue_update(e, fuse_pr && e->fuse_pr_enabled);
 }
 
 // ratio test (if the row is not known yet) + set-up + update for the candidate in `cand`
-int enqueue_pivot(lpamd_engine* e, bool find_row, Candidate* cand, const double* xcol, int64_t d_override) {
+int enqueue_pivot(lpamd_engine* e, bool find_row, Candidate* cand, const double* xcol, int64_t d_override, bool fuse_pr = false) {
   if (find_row) LP_TRY(enqueue_ratio_partial(e, false, cand, xcol));
-  return enqueue_finalize_update(e, find_row, cand, xcol, d_override);
+  return enqueue_finalize_update(e, find_row, cand, xcol, d_override, fuse_pr);
 }
 
 // One iteration of the main loop on one GPU: 4 launches for MAX_COST (pricing
@@ -267,7 +286,7 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
     return enqueue_finalize_update(e, true, e->cand, nullptr, -1);
   }
   LP_TRY(enqueue_pricing(e, strategy, e->cand));
-  return enqueue_finalize_update(e, false, e->cand, nullptr, -1);
+  return enqueue_finalize_update(e, false, e->cand, nullptr, -1, strategy == LPAMD_MAX_REDUCTION);
 }
 
 // Device-resident main loop: at most `budget` pivots (budget < 0: none).
@@ -381,6 +400,8 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_UPDATE_NT")) e->update_nt = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_UPDATE_UNROLL")) e->update_unroll_cap = std::max(1, atoi(env));
   if (const char* env = getenv("LPAMD_UPDATE_PREC")) e->update_prec = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_UPDATE_PREC_FUSED")) e->update_prec_fused = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_FUSE_PR")) e->fuse_pr_enabled = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_UPDATE_GRID")) e->update_grid = std::max(1, atoi(env));
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
@@ -400,6 +421,12 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMalloc(&e->active, sizeof(int32_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
+  HIP_TRY(hipMalloc(&e->pr_stamp, sizeof(int64_t) * e->ncl));
+  HIP_TRY(hipMalloc(&e->rhs_next, sizeof(double) * e->sh.lda));
+  HIP_TRY(hipMalloc(&e->cand_next, e->ncl));
+  HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
+  HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda, e->stream));
+  HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
   HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 3 * kMaxPartials));
@@ -421,7 +448,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T, e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->cand, e->part_v, e->part_i, e->st, e->trace};
+  void* ptrs[] = {e->T, e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->part_v, e->part_i, e->st, e->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -455,6 +482,7 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
   HIP_TRY(hipMemcpyAsync(e->is_basic, hb.data(), e->ncl, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->basis, basis.data(), sizeof(int64_t) * sh.m, hipMemcpyHostToDevice, e->stream));
   reset_state(e);
+  LP_TRY(invalidate_pr(e));
   LP_TRY(push_state(e));
   e->loaded = true;
   return LPAMD_OK;
@@ -469,6 +497,7 @@ int lpamd_fill_synthetic(lpamd_engine* e, int64_t n_struct, uint64_t seed) {
                      e->is_basic, e->basis, sh, n_struct, seed);
   LP_TRY(check_launch("k_fill_synthetic"));
   reset_state(e);
+  LP_TRY(invalidate_pr(e));
   LP_TRY(push_state(e));
   e->loaded = true;
   return LPAMD_OK;
@@ -646,6 +675,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));   // :71
   hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T + local_of(e, A) * sh.lda, m, 1.0);  // :82-86
   LP_TRY(check_launch("k_fill"));
+  LP_TRY(invalidate_pr(e));
   LP_TRY(lpamd_read_column(e, N, col.data()));
   int64_t r = -1;
   double mv = 0.0;
@@ -692,6 +722,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   }
   hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T + local_of(e, A) * sh.lda, m, 0.0);  // :143
   LP_TRY(check_launch("k_fill"));
+  LP_TRY(invalidate_pr(e));
   saved[A] = 0.0;
   // objective re-expression over the basic columns (:149-166)
   std::vector<double> acc(W, 0.0);
@@ -911,7 +942,7 @@ int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r,
   // may enqueue many pivots, so keep generous head-room (the trace stops recording when full).
   e->apply_since_pull++;
   LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
-  return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, (const double*)xbuf_dev, -1);
+  return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, (const double*)xbuf_dev, -1, strategy == LPAMD_MAX_REDUCTION);
 }
 
 int lpamd_poll(lpamd_engine* e, int32_t* result) {

@@ -177,17 +177,27 @@ __global__ __launch_bounds__(kPartialThreads) void k_price_fold(
 // rounded division is only executed for entries that can still beat the lane's
 // running minimum: for best > 0, b > best * (-a) * (1 + 2^-40) proves b / (-a) > best
 // for any rounding of the products and the quotient, so skipping those entries is exact.
-__device__ __forceinline__ void pr_consider(double a, double b, int64_t i, double& bv, int64_t& bi) {
+__device__ __forceinline__ void pr_consider(double a, double b, int64_t i, double bound, double& bv, int64_t& bi) {
   if ((float)a > -1e-6f) return;                 // _IsNonNegative (padding rows hold 0 and drop out here too)
   const double na = -a;
-  if (bv > 0.0 && b > __dmul_rn(__dmul_rn(bv, na), 1.0000000000009095)) return;
+  if (bound > 0.0 && b > __dmul_rn(__dmul_rn(bound, na), 1.0000000000009095)) return;
   const double ratio = b / na;
   if (bv > ratio) { bv = ratio; bi = i; }
 }
 
+// Smallest running minimum of the wavefront: an upper bound of the column's minimum
+// that every lane may use in the filter above (an entry whose ratio exceeds it is
+// strictly larger than the minimum, so it can be neither the arg-min nor a tie).
+__device__ __forceinline__ double wave_min_all(double v) {
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off, kWave));
+  return v;
+}
+
 __global__ __launch_bounds__(256) void k_pr_columns(
     const double* __restrict__ T, const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
-    Shape sh, const PivotState* __restrict__ st, double* __restrict__ cmin, int64_t* __restrict__ crow) {
+    Shape sh, const PivotState* __restrict__ st, double* __restrict__ cmin, int64_t* __restrict__ crow,
+    const int64_t* __restrict__ pr_stamp) {
   __shared__ double s_v[256 / kWave];
   __shared__ int64_t s_i[256 / kWave];
   if (st->status != ST_RUNNING) return;
@@ -196,10 +206,11 @@ __global__ __launch_bounds__(256) void k_pr_columns(
     if (threadIdx.x == 0) crow[l] = -2;
     return;
   }
+  if (pr_stamp[l] == st->iter) return;   // the last update already left this column's minimum ratio
   const double2* __restrict__ col = reinterpret_cast<const double2*>(T + (int64_t)l * sh.lda);
   const double2* __restrict__ rhs = reinterpret_cast<const double2*>(T + (int64_t)sh.nloc * sh.lda);
   const int n_vec = (int)(sh.lda / 2);           // multiple of 256
-  double bv = DBL_MAX;
+  double bv = DBL_MAX, bound = DBL_MAX;
   int64_t bi = -1;
   int v = threadIdx.x;
   for (; v + 3 * 256 < n_vec; v += 4 * 256) {
@@ -209,14 +220,15 @@ __global__ __launch_bounds__(256) void k_pr_columns(
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int64_t i = 2 * (int64_t)(v + u * 256);
-      pr_consider(a[u].x, b[u].x, i, bv, bi);
-      pr_consider(a[u].y, b[u].y, i + 1, bv, bi);
+      pr_consider(a[u].x, b[u].x, i, bound, bv, bi);
+      pr_consider(a[u].y, b[u].y, i + 1, bound, bv, bi);
     }
+    bound = wave_min_all(bv);
   }
   for (; v < n_vec; v += 256) {
     const double2 a = col[v], b = rhs[v];
-    pr_consider(a.x, b.x, 2 * (int64_t)v, bv, bi);
-    pr_consider(a.y, b.y, 2 * (int64_t)v + 1, bv, bi);
+    pr_consider(a.x, b.x, 2 * (int64_t)v, bound, bv, bi);
+    pr_consider(a.y, b.y, 2 * (int64_t)v + 1, bound, bv, bi);
   }
   block_arg<false, 256>(bv, bi, s_v, s_i);
   if (threadIdx.x == 0) { cmin[l] = bv; crow[l] = bi; }
@@ -352,7 +364,8 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
     int64_t d_override, PivotState* __restrict__ st, double* __restrict__ colp,
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
     double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
-    double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
+    double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
@@ -372,8 +385,14 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
   const double f = -1.0 / a;                         // lp_simplex_tableau.cc:40
   const double g = __dmul_rn(c.ce, f);               // lp_simplex_tableau.cc:34-35
   if ((int)blockIdx.x < n_row_blocks) {
-    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads)
-      colp[i] = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
+    const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+    const double rp_rhs = __dmul_rn(rhs[r], f);
+    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
+      const double cpi = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
+      colp[i] = cpi;
+      // right-hand side after this pivot (the update applies the same formula to the RHS replica)
+      rhs_next[i] = flushz(__dadd_rn(rhs[i], __dmul_rn(cpi, rp_rhs)));
+    }
     return;
   }
   // column workgroups: strided over the local columns so that any width fits kMaxPartials workgroups
@@ -398,7 +417,9 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
       act = rp != 0.0;
       if (l < sh.nloc) {
         const bool basic_next = l == l_e ? true : (l == l_d ? false : is_basic[l] != 0);
-        if (!basic_next && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
+        const bool candidate = !basic_next && is_pos(o);
+        cand_next[l] = candidate ? 1 : 0;
+        if (candidate && o > nbv) { nbv = o; nbi = l; }
       }
     }
     // wave-aggregated append to the active list
@@ -461,12 +482,18 @@ __device__ __forceinline__ double2 rank1(double2 t, double2 c, double rj) {
   return o;
 }
 
-template <int kUnroll, bool kNT, bool kPreC>
+// kFusePR: while a candidate column of the NEXT max-reduction pricing streams through
+// the registers, its minimum ratio b'_i / (-T'_ij) is taken on the updated values
+// (b' = rhs_next), which saves the separate 8*m*n read pass of k_pr_columns.
+template <int kUnroll, bool kNT, bool kPreC, bool kFusePR>
 __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register budget for 2*kUnroll 16-byte loads in flight
-
     double* __restrict__ T, int64_t lda, const double* __restrict__ colp,
     const double* __restrict__ rowp, const int32_t* __restrict__ active,
-    const PivotState* __restrict__ st, Shape sh, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
+    const PivotState* __restrict__ st, Shape sh, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
+    const double* __restrict__ rhs_next, const uint8_t* __restrict__ cand_next,
+    double* __restrict__ cmin, int64_t* __restrict__ crow, int64_t* __restrict__ pr_stamp) {
+  __shared__ double s_v[kUpdateThreads / kWave];
+  __shared__ int64_t s_i[kUpdateThreads / kWave];
   if (st->status != ST_RUNNING) return;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     // bookkeeping of reference lp_simplex_tableau.cc:16-28 for the pivot set up by k_pivot_finalize
@@ -481,10 +508,15 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   const int n_active = st->n_active;
   const int n_vec = (int)(lda / 2);                  // 16-byte vectors per column, a multiple of 256
   const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
+  const double2* __restrict__ bn = reinterpret_cast<const double2*>(rhs_next);
+  const int64_t stamp = st->iter;
   for (int k = blockIdx.x; k < n_active; k += gridDim.x) {
     const int l = active[k];
     const double rj = rowp[l];
     double2* __restrict__ p = reinterpret_cast<double2*>(T + (int64_t)l * lda);
+    const bool price = kFusePR && l < sh.nloc && cand_next[l] != 0;   // uniform over the workgroup
+    double bv = DBL_MAX, bound = DBL_MAX;
+    int64_t bi = -1;
     int v = threadIdx.x;
     for (; v + (kUnroll - 1) * kUpdateThreads < n_vec; v += kUnroll * kUpdateThreads) {
       double2 t[kUnroll], c[kUnroll];
@@ -500,10 +532,37 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
         if (!kPreC) c[u] = cp[v + u * kUpdateThreads];
-        st16<kNT>(p + v + u * kUpdateThreads, rank1(t[u], c[u], rj));
+        t[u] = rank1(t[u], c[u], rj);
+        st16<kNT>(p + v + u * kUpdateThreads, t[u]);
+      }
+      if (kFusePR && price) {
+        // third phase, after the whole store burst has been issued: the updated values are
+        // still in registers, the new right-hand side comes from L2
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) c[u] = bn[v + u * kUpdateThreads];
+#pragma unroll
+        for (int u = 0; u < kUnroll; u++) {
+          const int64_t i = 2 * (int64_t)(v + u * kUpdateThreads);
+          pr_consider(t[u].x, c[u].x, i, bound, bv, bi);
+          pr_consider(t[u].y, c[u].y, i + 1, bound, bv, bi);
+        }
+        bound = wave_min_all(bv);
       }
     }
-    for (; v < n_vec; v += kUpdateThreads) st16<kNT>(p + v, rank1(ld16<kNT>(p + v), cp[v], rj));
+    for (; v < n_vec; v += kUpdateThreads) {
+      const double2 o = rank1(ld16<kNT>(p + v), cp[v], rj);
+      st16<kNT>(p + v, o);
+      if (kFusePR && price) {
+        const double2 b = bn[v];
+        pr_consider(o.x, b.x, 2 * (int64_t)v, bound, bv, bi);
+        pr_consider(o.y, b.y, 2 * (int64_t)v + 1, bound, bv, bi);
+      }
+    }
+    if (kFusePR && price) {
+      block_arg<false, kUpdateThreads>(bv, bi, s_v, s_i);
+      if (threadIdx.x == 0) { cmin[l] = bv; crow[l] = bi; pr_stamp[l] = stamp; }
+    }
   }
 }
 
