@@ -104,3 +104,50 @@ def test_unbounded_and_infeasible(lpamd):
     assert eng.solve(lpamd.MAX_COST)[0] == lpamd.NOSOLUTION
     assert dt.solve(lo.MAX_COST) == lo.NOSOLUTION
     eng.close()
+
+
+def _random_tied_lp(rng, n_vars, n_cons):
+    """Small-integer coefficients: many equal reduced costs and equal ratios, so the
+    lowest-index tie-breaks of pricing and of the ratio test decide the path."""
+    names = ["v%d" % k for k in range(n_vars)]
+    obj = " + ".join("%d * %s" % (rng.integers(1, 4), v) for v in names)
+    lines = ["max " + obj, "st"]
+    for _ in range(n_cons):
+        picks = rng.choice(n_vars, size=rng.integers(2, min(6, n_vars) + 1), replace=False)
+        lhs = " + ".join("%d * %s" % (rng.integers(1, 4), names[k]) for k in sorted(picks))
+        lines.append("%s <= %d" % (lhs, rng.integers(2, 7)))
+    if rng.integers(0, 2):                       # an equality and a >= row force phase 1
+        lines.append("%s + %s = %d" % (names[0], names[1], rng.integers(1, 3)))
+        lines.append("%s >= 1" % names[2 % n_vars])
+    lines += ["%s >= 0" % v for v in names]
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lps_with_ties(lpamd, seed):
+    rng = np.random.default_rng(seed)
+    text = _random_tied_lp(rng, int(rng.integers(3, 12)), int(rng.integers(2, 10)))
+    for strategy in ("max_cost", "max_reduction"):
+        tab, dt = lo.from_text(text)
+        want = dt.solve(lo.STRATEGY[strategy])
+        eng = lpamd.TableauEngine(tab.m, tab.N)
+        eng.upload(tab.T, tab.obj, tab.is_basic)
+        res, n = eng.solve(lpamd.STRATEGY[strategy])
+        assert res == want, text
+        assert eng.trace() == dt.trace(), text
+        assert_same_tableau(eng, dt)
+        eng.close()
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 5), (3, 1), (511, 2), (512, 3), (513, 3), (2, 700)])
+def test_extreme_shapes(lpamd, m, n):
+    dt = lo.DenseTableau.synthetic(m, n, 2)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, 2)
+    for strategy in ("max_reduction", "max_cost"):
+        res, _ = eng.run_pivots(lpamd.STRATEGY[strategy], 3)
+        want = dt.solve(lo.STRATEGY[strategy], max_pivots=dt.n_pivots + 3)
+        assert res == want
+        assert eng.trace() == dt.trace()
+        assert_same_tableau(eng, dt)
+    eng.close()
