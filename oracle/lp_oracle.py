@@ -156,3 +156,94 @@ def solve_text(text, strategy="max_cost"):
     if res == SOLVED:
         return fe.format_solution(tab, dt.column_values(), dt.obj[tab.N]), dt
     return RESULT_TEXT.get(res, "Error\n"), dt
+
+
+# ---------------------------------------------------------------- revised simplex
+class _LpoRevT(ctypes.Structure):
+    _fields_ = [
+        ("m", ctypes.c_int64), ("N", ctypes.c_int64), ("ncols", ctypes.c_int64), ("lda", ctypes.c_int64),
+        ("T", ctypes.c_void_p), ("obj", ctypes.c_void_p), ("is_basic", ctypes.c_void_p), ("basis", ctypes.c_void_p),
+        ("Binv", ctypes.c_void_p), ("xB", ctypes.c_void_p), ("cB", ctypes.c_void_p),
+        ("opt_reverted", ctypes.c_int32), ("optimum", ctypes.c_double),
+        ("trace_e", ctypes.c_void_p), ("trace_l", ctypes.c_void_p),
+        ("trace_cap", ctypes.c_int64), ("n_pivots", ctypes.c_int64), ("max_pivots", ctypes.c_int64),
+    ]
+
+
+class RevisedTableau:
+    """Dense state of the revised simplex on the tableau (reference
+    lp_revised_simplex_tableau.cc), driven by lpo_revised_solve."""
+
+    def __init__(self, T, obj, is_basic, N, opt_reverted, trace_cap=1 << 16):
+        m = T.shape[0]
+        self.m, self.N = m, N
+        W = N + 1 + m
+        self.T = np.zeros((m, W), dtype=np.float64, order="F")
+        self.T[:, : N + 1] = T[:, : N + 1]
+        self.obj = np.zeros(W, dtype=np.float64)
+        self.obj[: N + 1] = obj[: N + 1]
+        self.is_basic = np.zeros(W, dtype=np.uint8)
+        self.is_basic[:N] = is_basic[:N]
+        self.basis = np.array([j for j in range(N) if is_basic[j]], dtype=np.int64)   # Variable order == column order
+        assert len(self.basis) == m
+        self.Binv = np.zeros((m, m), dtype=np.float64)
+        self.xB = np.zeros(m, dtype=np.float64)
+        self.cB = np.zeros(m, dtype=np.float64)
+        self.trace_e = np.full(trace_cap, -1, dtype=np.int64)
+        self.trace_l = np.full(trace_cap, -1, dtype=np.int64)
+        s = self.s = _LpoRevT()
+        s.m, s.N, s.ncols, s.lda = m, N, W, max(m, 1)
+        s.T, s.obj, s.is_basic, s.basis = self.T.ctypes.data, self.obj.ctypes.data, self.is_basic.ctypes.data, self.basis.ctypes.data
+        s.Binv, s.xB, s.cB = self.Binv.ctypes.data, self.xB.ctypes.data, self.cB.ctypes.data
+        s.opt_reverted = 1 if opt_reverted else 0
+        s.optimum = 0.0
+        s.trace_e, s.trace_l = self.trace_e.ctypes.data, self.trace_l.ctypes.data
+        s.trace_cap, s.n_pivots, s.max_pivots = trace_cap, 0, -1
+        L = lib()
+        L.lpo_revised_solve.argtypes = [ctypes.POINTER(_LpoRevT)]
+        L.lpo_revised_solve.restype = ctypes.c_int
+
+    def solve(self, max_pivots=-1):
+        self.s.max_pivots = max_pivots
+        return lib().lpo_revised_solve(ctypes.byref(self.s))
+
+    @property
+    def n_pivots(self):
+        return int(self.s.n_pivots)
+
+    @property
+    def optimum(self):
+        return float(self.s.optimum)
+
+    def trace(self):
+        k = min(self.n_pivots, len(self.trace_e))
+        return list(zip(self.trace_e[:k].tolist(), self.trace_l[:k].tolist()))
+
+    def column_values(self):
+        x = np.zeros(self.N + 2, dtype=np.float64)
+        for i in range(self.m):
+            if self.basis[i] < self.N:
+                x[self.basis[i]] = self.xB[i]
+        return x
+
+
+def revised_from_text(text, **kw):
+    tab = fe.build_tableau(text)
+    return tab, RevisedTableau(tab.T, tab.obj, tab.is_basic, tab.N, tab.opt_reverted, **kw)
+
+
+def format_revised(tab, rt):
+    """stdout of `solver <file> revised_simplex_tableau` (solver.cc:135-171): the optimum
+    already carries its sign (lp_revised_simplex_tableau.cc:253-257)."""
+    import copy
+    t2 = copy.copy(tab)
+    t2.opt_reverted = False
+    return fe.format_solution(t2, rt.column_values(), rt.optimum)
+
+
+def solve_text_revised(text):
+    tab, rt = revised_from_text(text)
+    res = rt.solve()
+    if res == SOLVED:
+        return format_revised(tab, rt), rt
+    return RESULT_TEXT.get(res, "Error\n"), rt

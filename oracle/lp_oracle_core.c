@@ -390,3 +390,215 @@ void lpo_synth_fill(lpo_t *p, uint64_t seed, int64_t n) {
   if (p->basis_of_row)
     for (int64_t i = 0; i < m; i++) p->basis_of_row[i] = n + i;
 }
+
+/* ======================================================================
+ * Revised simplex on the tableau (reference lp_revised_simplex_tableau.cc).
+ * Dense restatement: the basis inverse is a dense m x m matrix (row i = basis
+ * position i, column = constraint row), sums over the contracted index run in
+ * ascending order with every product and sum rounded separately and no zero
+ * drop inside the accumulation; the zero drop (flushz) applies to the result of
+ * List/Tableau::Add only, i.e. to the reduced costs (:238) and to the rank-1
+ * update of the inverse (:61), not to basic_feasible_solution->AddScaled (:52).
+ * This is the variant that reproduces all seven revised-simplex goldens of the
+ * reference byte for byte (tests/sol{15,16,17}_revised_simplex_tableau.txt,
+ * datasets/netlib_revised_simplex_sol/{afiro,adlittle,kb2,israel}.txt).
+ * ====================================================================== */
+typedef struct {
+  int64_t m, N;        /* rows; variables (RHS column index = N) */
+  int64_t ncols;       /* allocated columns: N + 1 + m (artificials at N+1 .. N+m) */
+  int64_t lda;
+  double *T;           /* lda * ncols, column-major */
+  double *obj;         /* ncols */
+  uint8_t *is_basic;   /* ncols */
+  int64_t *basis;      /* m: in = initial basis columns in Variable order, out = final basis */
+  double *Binv;        /* m * m, row-major */
+  double *xB, *cB;     /* m */
+  int32_t opt_reverted;/* in/out */
+  double optimum;      /* out */
+  int64_t *trace_e, *trace_l;   /* entering column, leaving basis position */
+  int64_t trace_cap, n_pivots, max_pivots;
+} lpo_rev_t;
+
+static void rev_init_basis(lpo_rev_t *p, int64_t ncols_active) {
+  const int64_t m = p->m, lda = p->lda, N = p->N;
+  (void)ncols_active;
+  /* reference :212-233.  The basis matrix is a signed permutation here (slack or
+   * artificial columns), so its inverse is the transpose scaled by 1/entry. */
+  memset(p->Binv, 0, sizeof(double) * (size_t)m * (size_t)m);
+  for (int64_t i = 0; i < m; i++) {
+    const int64_t b = p->basis[i];
+    p->cB[i] = p->obj[b];
+    p->xB[i] = 0.0;
+    for (int64_t r = 0; r < m; r++) {
+      const double v = p->T[r + b * lda];
+      if (!is_zero(v)) {
+        p->xB[i] = p->T[r + N * lda] / (-v);             /* :223-225 */
+        p->Binv[i * m + r] = 1.0 / (-v);                  /* inverse of the permutation column */
+        break;
+      }
+    }
+  }
+}
+
+/* reference :42-62 */
+static void rev_pivot(lpo_rev_t *p, int64_t leaving, int64_t e, double *mu, double ratio) {
+  const int64_t m = p->m;
+  p->is_basic[e] = 1;
+  p->is_basic[p->basis[leaving]] = 0;
+  for (int64_t i = 0; i < m; i++) p->xB[i] = p->xB[i] + mu[i] * ratio;   /* AddScaled, no zero drop */
+  p->xB[leaving] = ratio;
+  p->basis[leaving] = e;
+  p->cB[leaving] = p->obj[e];
+  double *rowl = p->Binv + leaving * m;
+  const double s = -1.0 / mu[leaving];
+  for (int64_t k = 0; k < m; k++) rowl[k] = rowl[k] * s;
+  mu[leaving] = 0.0;
+  /* dense view of Tableau::Add (:61): Binv = flush(Binv + mu (x) scaled row).  The zero
+   * drop reaches every entry, also rows with mu[i] == 0 and the scaled leaving row
+   * itself (needed for the israel golden), so the scaled row is copied first. */
+  double *scaled = (double *)malloc(sizeof(double) * (size_t)m);
+  memcpy(scaled, rowl, sizeof(double) * (size_t)m);
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < m; i++) {
+    const double mi = mu[i];
+    double *row = p->Binv + i * m;
+    for (int64_t k = 0; k < m; k++) row[k] = flushz(row[k] + mi * scaled[k]);
+  }
+  free(scaled);
+  if (p->trace_e && p->n_pivots < p->trace_cap) {
+    p->trace_e[p->n_pivots] = e;
+    p->trace_l[p->n_pivots] = leaving;
+  }
+  p->n_pivots++;
+}
+
+/* mu = Binv * T[:, col]  (Tableau::Times, :155 and :280): ascending constraint row */
+static void rev_times(const lpo_rev_t *p, int64_t col, double *mu) {
+  const int64_t m = p->m;
+  const double *c = p->T + col * p->lda;
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < m; i++) {
+    double acc = 0.0;
+    const double *row = p->Binv + i * m;
+    for (int64_t r = 0; r < m; r++) acc = acc + row[r] * c[r];
+    mu[i] = acc;
+  }
+}
+
+static void rev_optimum(lpo_rev_t *p) {   /* :253-257 */
+  double v = p->obj[p->N];
+  for (int64_t i = 0; i < p->m; i++) v += p->obj[p->basis[i]] * p->xB[i];
+  if (p->opt_reverted) v *= -1;
+  p->optimum = v;
+}
+
+/* reference :235-300 */
+static int rev_main_loop(lpo_rev_t *p, int64_t ncols_active) {
+  const int64_t m = p->m, lda = p->lda, N = p->N;
+  double *pv = (double *)malloc(sizeof(double) * (size_t)m);
+  double *cost = (double *)malloc(sizeof(double) * (size_t)ncols_active);
+  double *mu = (double *)malloc(sizeof(double) * (size_t)m);
+  int rc = LPO_ERROR;
+  for (;;) {
+    if (p->max_pivots >= 0 && p->n_pivots >= p->max_pivots) { rc = LPO_LIMIT; break; }
+    /* p = sum_i cB[i] * Binv[i, :]   (:236) */
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < m; r++) {
+      double acc = 0.0;
+      for (int64_t i = 0; i < m; i++) acc = acc + p->cB[i] * p->Binv[i * m + r];
+      pv[r] = acc;
+    }
+    /* cost = obj + sum_r p[r] * T[r, :]   (:237-238), zero drop on the sum */
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < ncols_active; j++) {
+      const double *col = p->T + j * lda;
+      double acc = 0.0;
+      for (int64_t r = 0; r < m; r++) acc = acc + pv[r] * col[r];
+      cost[j] = flushz(p->obj[j] + acc);
+    }
+    int64_t e = -1;
+    double best = DBL_MAX;
+    for (int64_t j = 0; j < ncols_active; j++) {       /* :242-251 */
+      if (j == N || p->is_basic[j]) continue;
+      if (is_nonneg(cost[j])) continue;
+      if (best > cost[j]) { best = cost[j]; e = j; }
+    }
+    if (e < 0) { rev_optimum(p); rc = LPO_SOLVED; break; }
+    rev_times(p, e, mu);                                 /* :280 */
+    int64_t leaving = -1;
+    double mr = DBL_MAX;
+    for (int64_t i = 0; i < m; i++) {                    /* :284-291 */
+      if (is_neg(mu[i]) && -(p->xB[i] / mu[i]) < mr) { mr = -p->xB[i] / mu[i]; leaving = i; }
+    }
+    if (leaving < 0) { rc = LPO_UNBOUNDED; break; }
+    rev_pivot(p, leaving, e, mu, mr);
+  }
+  free(pv);
+  free(cost);
+  free(mu);
+  return rc;
+}
+
+/* reference :199-302 with :92-197 inlined for the phase-1 branch */
+int lpo_revised_solve(lpo_rev_t *p) {
+  const int64_t m = p->m, lda = p->lda, N = p->N, W0 = N + 1;
+  for (int64_t j = 0; j < W0; j++) p->obj[j] = p->obj[j] * -1.0;   /* :201 */
+  p->opt_reverted = !p->opt_reverted;                              /* :202 */
+  int need = 0;
+  for (int64_t i = 0; i < m; i++) need |= is_neg(p->T[i + N * lda]);
+  if (!need) {
+    rev_init_basis(p, W0);
+    return rev_main_loop(p, W0);
+  }
+  /* phase 1: rows with a negative right-hand side are negated (:95-114) */
+  for (int64_t i = 0; i < m; i++) {
+    if (!is_neg(p->T[i + N * lda])) continue;
+    for (int64_t j = 0; j < W0; j++) p->T[i + j * lda] = -1 * p->T[i + j * lda];
+  }
+  double *raw_obj = (double *)malloc(sizeof(double) * (size_t)p->ncols);
+  memcpy(raw_obj, p->obj, sizeof(double) * (size_t)p->ncols);
+  const int raw_rev = p->opt_reverted;
+  int64_t *saved_basis = NULL;
+  (void)saved_basis;
+  for (int64_t j = 0; j < p->ncols; j++) { p->obj[j] = 0.0; p->is_basic[j] = 0; }
+  for (int64_t i = 0; i < m; i++) {                                /* :127-137 */
+    const int64_t c = W0 + i;
+    for (int64_t r = 0; r < m; r++) p->T[r + c * lda] = 0.0;
+    p->T[i + c * lda] = -1.0;
+    p->obj[c] = -1.0;
+    p->is_basic[c] = 1;
+    p->basis[i] = c;
+  }
+  /* nested TableauRevisedSimplexSolve (:139): negate the auxiliary objective */
+  for (int64_t j = 0; j < p->ncols; j++) p->obj[j] = p->obj[j] * -1.0;
+  p->opt_reverted = !p->opt_reverted;
+  rev_init_basis(p, p->ncols);
+  int rc = rev_main_loop(p, p->ncols);
+  if (rc == LPO_LIMIT) { free(raw_obj); return rc; }
+  if (rc != LPO_SOLVED) { free(raw_obj); return LPO_ERROR; }      /* :140 live assert */
+  if (!is_zero(p->optimum)) { free(raw_obj); return LPO_NOSOLUTION; }   /* :142 */
+  double *probing = (double *)malloc(sizeof(double) * (size_t)m);
+  for (int64_t i = 0; i < m; i++) {                                /* :145-170 */
+    if (p->basis[i] < N) continue;      /* only artificial columns (index >= N + 1) qualify */
+    int pivoted = 0;
+    for (int64_t col = 0; col < W0 && !pivoted; col++) {
+      if (col == N || p->is_basic[col]) continue;
+      rev_times(p, col, probing);
+      if (!is_zero(probing[i])) {
+        rev_pivot(p, i, col, probing, -(p->xB[i] / probing[i]));
+        pivoted = 1;
+      }
+    }
+    if (!pivoted) { free(probing); free(raw_obj); return LPO_ERROR; }   /* :165 live assert */
+  }
+  free(probing);
+  for (int64_t c = W0; c < p->ncols; c++) {                        /* :171 */
+    for (int64_t r = 0; r < m; r++) p->T[r + c * lda] = 0.0;
+    p->is_basic[c] = 0;
+  }
+  memcpy(p->obj, raw_obj, sizeof(double) * (size_t)p->ncols);      /* :192-193 */
+  p->opt_reverted = raw_rev;
+  free(raw_obj);
+  for (int64_t i = 0; i < m; i++) p->cB[i] = p->obj[p->basis[i]];  /* :194-195 */
+  return rev_main_loop(p, W0);
+}

@@ -50,3 +50,15 @@ def case_text(name):
 
 def case_golden(name, strategy):
     return lp_golden(int(name[4:]), strategy) if name.startswith("test") else netlib_golden(name, strategy)
+
+
+# revised simplex on the tableau: reference CMakeLists.txt:105-114 and 138-144
+REVISED_CASES = [("test12", "lp/sol12.txt"), ("test13", "lp/sol13.txt"), ("test14", "lp/sol14.txt"),
+                 ("test15", "lp/sol15_revised_simplex_tableau.txt"), ("test16", "lp/sol16_revised_simplex_tableau.txt"),
+                 ("test17", "lp/sol17_revised_simplex_tableau.txt"), ("afiro", "netlib_sol_revised/afiro.txt"),
+                 ("kb2", "netlib_sol_revised/kb2.txt"), ("adlittle", "netlib_sol_revised/adlittle.txt"),
+                 ("israel", "netlib_sol_revised/israel.txt")]
+
+
+def revised_golden(rel):
+    return open(os.path.join(GOLDEN, rel)).read()

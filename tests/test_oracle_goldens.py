@@ -95,3 +95,12 @@ def test_unbounded_infeasible_empty_objective():
     assert lo.solve_text("max x1\nst\nx1 <= 1\nx1 >= 2\nx1 >= 0\n")[0] == "No Solution\n"
     # degenerate: objective mentions no constrained variable -> already optimal
     assert lo.solve_text("max 0 * x1\nst\nx1 <= 1\nx1 >= 0\n")[0].startswith("0.000000\n")
+
+
+from cases import REVISED_CASES, revised_golden
+
+
+@pytest.mark.parametrize("name,golden", REVISED_CASES)
+def test_revised_oracle_reproduces_reference_golden(name, golden):
+    out, rt = lo.solve_text_revised(case_text(name))
+    assert out.rstrip("\n") == revised_golden(golden).rstrip("\n")
