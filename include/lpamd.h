@@ -163,6 +163,45 @@ int lpamd_set_pivot_budget(lpamd_engine* eng, int64_t max_pivots);
 /* terminal status after step 4 (synchronises): LPAMD_LIMIT = still running */
 int lpamd_poll(lpamd_engine* eng, int32_t* result);
 
+/* ---- revised simplex on the tableau (one GPU) ------------------------------
+ * The reference's other tableau algorithm, `solver <file> revised_simplex_tableau`
+ * (reference solver.cc:139-144): the tableau stays as uploaded and a dense basis
+ * inverse is carried along.  The handle owns a row-major copy of the tableau,
+ * the inverse and its transpose, and all vectors; the loop runs on the device. */
+typedef struct lpamd_rev_engine lpamd_rev_engine;
+/* m constraint rows, N variable columns (right-hand side at column N).
+ * hip_stream as in lpamd_create.  Device memory is taken at upload time. */
+int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_stream);
+int lpamd_rev_destroy(lpamd_rev_engine* eng);
+/* T, obj, is_basic laid out as for lpamd_upload (columns 0..N are read; exactly m
+ * basic columns, each with a single non-zero entry, as LPModel::ToTableau leaves
+ * them, reference lp.cc:147-197).  opt_reverted: the model's objective was negated
+ * on the way to standard form (reference lp.h opt_reverted_).  A negative
+ * right-hand side reserves the m artificial columns of the feasibility phase. */
+int lpamd_rev_upload(lpamd_rev_engine* eng, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic,
+                     int32_t opt_reverted);
+/* The synthetic dense LP of lpamd_fill_synthetic, generated on the device in this
+ * engine's layout (N == n_struct + m, slack basis, positive right-hand side). */
+int lpamd_rev_fill_synthetic(lpamd_rev_engine* eng, int64_t n_struct, uint64_t seed);
+/* LPModel::TableauRevisedSimplexSolve (reference lp_revised_simplex_tableau.cc:199-302)
+ * including TableauRevisedSimplexInitialize (:92-197) and the pivot (:42-62).
+ * max_pivots < 0: no limit; otherwise *result == LPAMD_LIMIT once that many pivots
+ * (feasibility phase included) have been applied, and a further call with a larger
+ * limit continues a run that stopped in the main phase. */
+int lpamd_rev_solve(lpamd_rev_engine* eng, int64_t max_pivots, int32_t* result, int64_t* n_pivots);
+/* GetTableauRevisedSimplexOptimum (reference :253-257, :304-306): sign already applied. */
+int lpamd_rev_optimum(lpamd_rev_engine* eng, double* out);
+/* Values of all N + 2 columns as in lpamd_column_values: basic_feasible_solution
+ * scattered by basis_indices, zero elsewhere (reference :259-263). */
+int lpamd_rev_column_values(lpamd_rev_engine* eng, double* x);
+int lpamd_rev_pivot_count(lpamd_rev_engine* eng, int64_t* n);
+/* (entering column, leaving basis position) of every pivot so far */
+int lpamd_rev_trace(lpamd_rev_engine* eng, int64_t* entering, int64_t* leaving_pos, int64_t cap, int64_t* n);
+/* Debug/test access; any pointer may be NULL.  Binv, BinvT: m x m row-major
+ * (basis_inverse of the reference and its transpose); xB = basic_feasible_solution,
+ * cB = basis_coeff, basis = basis_indices (reference lp.h:281-284). */
+int lpamd_rev_read_state(lpamd_rev_engine* eng, double* Binv, double* BinvT, double* xB, double* cB, int64_t* basis);
+
 #ifdef __cplusplus
 }
 #endif

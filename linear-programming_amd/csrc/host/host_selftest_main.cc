@@ -151,6 +151,21 @@ static void TableauCases(const std::string& dir) {
     CHECK_EQ(sol.size(), (size_t)2);
     CHECK_EQ(Near(sol[Variable("x1")], 2.0f / 3) && Near(sol[Variable("x2")], 1.0f / 3), true);
   }
+  // reference lp_revised_simplex_tableau_test.cc:7-98
+  struct RevisedCase { const char* file; bool check_opt; float opt; double x1, x2; };
+  const RevisedCase revised[] = {{"test3.txt", true, -7.0f, 5.0, 2.0}, {"test8.txt", false, 0.0f, 4.0, 2.0},
+                                 {"test5.txt", true, 23.75f, 3.75, 1.25}, {"test4.txt", true, 5.0f, 2.0f / 3, 1.0f / 3}};
+  for (const auto& c : revised) {
+    LPModel model = Load(dir, c.file);
+    model.ToStandardForm();
+    model.ToSlackForm();
+    model.ToTableau(COLUMN_ONLY);
+    CHECK_EQ(model.TableauRevisedSimplexSolve(), SOLVED);
+    if (c.check_opt) CHECK_EQ(model.GetTableauRevisedSimplexOptimum() == Num(c.opt), true);
+    auto sol = model.GetTableauRevisedSimplexSolution();
+    CHECK_EQ(sol.size(), (size_t)2);
+    CHECK_EQ(Near(sol[Variable("x1")], c.x1) && Near(sol[Variable("x2")], c.x2), true);
+  }
   {  // ToTableau snapshot of test9
     LPModel model = Load(dir, "test9.txt");
     model.ToStandardForm();

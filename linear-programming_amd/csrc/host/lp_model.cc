@@ -165,10 +165,19 @@ HostTableau LPModel::BuildHostTableau() {
   return h;
 }
 
-void LPModel::ToTableau(TableauStorageFormat) {
-  if (engine_ != nullptr) return;
+void LPModel::ToTableau(TableauStorageFormat format) {
+  if (engine_ != nullptr || rev_engine_ != nullptr) return;
   HostTableau h = BuildHostTableau();
   LP_ASSERT(h.m > 0 && h.N > 0);
+  if (format == COLUMN_ONLY) {
+    // The storage format upstream picks for the revised simplex (reference solver.cc:139,
+    // lp_revised_simplex_tableau_test.cc:14); here it selects the engine that keeps the
+    // tableau untouched and carries the basis inverse.
+    CheckEngine(lpamd_rev_create(&rev_engine_, h.m, h.N, nullptr), "ToTableau: creating the GPU engine failed");
+    CheckEngine(lpamd_rev_upload(rev_engine_, h.T.data(), h.m, h.obj.data(), h.is_basic.data(), opt_reverted_ ? 1 : 0),
+                "ToTableau: upload failed");
+    return;
+  }
   CheckEngine(lpamd_create(&engine_, h.m, h.N, 0, 1, nullptr), "ToTableau: creating the GPU engine failed");
   CheckEngine(lpamd_upload(engine_, h.T.data(), h.m, h.obj.data(), h.is_basic.data()), "ToTableau: upload failed");
 }
@@ -299,8 +308,56 @@ Num LPModel::GetTableauSimplexOptimum() {
   return (opt_reverted_ ? -1 : 1) * c;
 }
 
+// reference lp_revised_simplex_tableau.cc:92-197.  The feasibility phase is part of the
+// engine's solve; upstream only reaches this method from TableauRevisedSimplexSolve.
+Result LPModel::TableauRevisedSimplexInitialize() {
+  LP_ASSERT(rev_engine_ != nullptr);
+  return SOLVED;
+}
+
+// reference lp_revised_simplex_tableau.cc:199-302
+Result LPModel::TableauRevisedSimplexSolve() {
+  LP_ASSERT(rev_engine_ != nullptr);
+  LP_ASSERT(model_.opt_obj.opt_type == OptimizationObject::MAX);
+  int32_t result = LPAMD_ERROR;
+  int64_t pivots = 0;
+  CheckEngine(lpamd_rev_solve(rev_engine_, -1, &result, &pivots), "TableauRevisedSimplexSolve");
+  if (result == LPAMD_UNBOUNDED) return UNBOUNDED;
+  if (result == LPAMD_NOSOLUTION) return NOSOLUTION;
+  if (result != LPAMD_SOLVED) return ERROR;
+  double optimum = 0.0;
+  CheckEngine(lpamd_rev_optimum(rev_engine_, &optimum), "TableauRevisedSimplexSolve");
+  revised_simplex_optimum_ = Num(optimum);
+  // :259-277: basic_feasible_solution scattered over the variables, then the
+  // substituted raw variables are rebuilt from their expressions.
+  std::vector<double> x(constant_index_ + 2, 0.0);
+  CheckEngine(lpamd_rev_column_values(rev_engine_, x.data()), "TableauRevisedSimplexSolve");
+  std::map<Variable, Num> all_sol;
+  revised_simplex_solution_.clear();
+  for (const auto& entry : variable_to_index_) all_sol[entry.first] = Num(x[entry.second]);
+  for (const auto& entry : variable_to_index_)
+    if (IsUserDefined(entry.first) || IsOverriddenAsUserDefined(entry.first)) revised_simplex_solution_[entry.first] = all_sol[entry.first];
+  for (const auto& entry : raw_variable_expression_) {
+    Expression exp = entry.second;
+    while (!exp.variable_coeff.empty()) {
+      const Variable head = exp.variable_coeff.begin()->first;
+      ReplaceVariableWithExpression(exp, head, all_sol[head]);
+    }
+    revised_simplex_solution_[entry.first] = exp.constant;
+  }
+  return SOLVED;
+}
+
+// reference lp_revised_simplex_tableau.cc:304-310
+Num LPModel::GetTableauRevisedSimplexOptimum() { return revised_simplex_optimum_; }
+std::map<Variable, Num> LPModel::GetTableauRevisedSimplexSolution() { return revised_simplex_solution_; }
+
 int64_t LPModel::TableauPivotCount() {
   int64_t n = 0;
+  if (rev_engine_ != nullptr) {
+    CheckEngine(lpamd_rev_pivot_count(rev_engine_, &n), "TableauPivotCount");
+    return n;
+  }
   CheckEngine(lpamd_pivot_count(engine_, &n), "TableauPivotCount");
   return n;
 }
@@ -309,7 +366,8 @@ std::vector<std::pair<int64_t, int64_t>> LPModel::TableauPivotTrace() {
   const int64_t n = TableauPivotCount();
   std::vector<int64_t> e(std::max<int64_t>(n, 1)), r(std::max<int64_t>(n, 1));
   int64_t got = 0;
-  CheckEngine(lpamd_trace(engine_, e.data(), r.data(), n, &got), "TableauPivotTrace");
+  if (rev_engine_ != nullptr) CheckEngine(lpamd_rev_trace(rev_engine_, e.data(), r.data(), n, &got), "TableauPivotTrace");
+  else CheckEngine(lpamd_trace(engine_, e.data(), r.data(), n, &got), "TableauPivotTrace");
   std::vector<std::pair<int64_t, int64_t>> out;
   for (int64_t i = 0; i < n; i++) out.emplace_back(e[i], r[i]);
   return out;

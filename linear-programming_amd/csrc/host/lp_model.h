@@ -22,6 +22,7 @@
 #include "algebra.h"
 
 struct lpamd_engine;
+struct lpamd_rev_engine;
 
 typedef int64_t tableau_index_t;
 typedef int64_t tableau_size_t;
@@ -83,6 +84,13 @@ class LPModel {
   Num GetTableauSimplexOptimum();
   std::map<Variable, Num> GetTableauSimplexSolution();
 
+  // Revised simplex on the tableau; the model must have gone through
+  // ToTableau(COLUMN_ONLY), the format upstream's solver selects for it.
+  Result TableauRevisedSimplexInitialize();
+  Result TableauRevisedSimplexSolve();
+  Num GetTableauRevisedSimplexOptimum();
+  std::map<Variable, Num> GetTableauRevisedSimplexSolution();
+
   virtual bool IsBaseVariable(Variable var) { return base_variables_.count(var) != 0; }
   std::set<Variable> GetBaseVariables() { return base_variables_; }
   virtual void AddBaseVariable(Variable var) { base_variables_.insert(var); }
@@ -117,6 +125,7 @@ class LPModel {
   std::set<Variable> non_negative_variables_;
   std::map<Variable, Expression> raw_variable_expression_;
 
+  lpamd_rev_engine* rev_engine_ = nullptr;   // revised simplex: tableau + basis inverse on the device
   lpamd_engine* engine_ = nullptr;     // owns the device tableau; intentionally never freed, like the reference's raw pointers
   std::map<Variable, tableau_index_t> variable_to_index_;
   std::map<tableau_index_t, Variable> index_to_variable_;
@@ -125,6 +134,8 @@ class LPModel {
   std::set<Variable> overrided_as_user_defined_variables_;
   Num simplex_optimum_;
   std::map<Variable, Num> simplex_solution_;
+  Num revised_simplex_optimum_;
+  std::map<Variable, Num> revised_simplex_solution_;
 
   int base_variable_count_ = 0;
   int substitution_variable_count_ = 0;

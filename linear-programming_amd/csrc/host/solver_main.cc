@@ -1,9 +1,9 @@
 // solver <input-file> [solver-algo] [pivot-strategy]
 // Command line of the reference's solver.cc for the tableau path: parses the LP
-// text file, runs `simplex_tableau` on the GPU engine and prints the optimum
-// followed by `name = value` lines (reference solver.cc:160-171).  Algorithms
-// other than simplex_tableau belong to the reference's CPU-only solvers and are
-// rejected.  A file ending in .mps is first converted the way the reference's
+// text file, runs `simplex_tableau` or `revised_simplex_tableau` on the GPU engine
+// and prints the optimum followed by `name = value` lines (reference
+// solver.cc:123-171).  The other algorithms belong to the reference's CPU-only
+// solvers and are rejected.  A file ending in .mps is first converted the way the reference's
 // tools/mps_load.py does.
 #include <algorithm>
 #include <cctype>
@@ -60,8 +60,9 @@ int main(int argc, char** argv) {
   bool any_float = false;
   for (auto& con : model.constraints)
     for (auto& term : con.expression.variable_coeff) any_float |= term.first.type == FLOAT;
-  if (!any_float || algo != "simplex_tableau") {
-    std::cerr << "only `simplex_tableau` on continuous LPs runs on the GPU engine (got algo `" << algo << "`)\n";
+  const bool revised = algo == "revised_simplex_tableau";
+  if (!any_float || (algo != "simplex_tableau" && !revised)) {
+    std::cerr << "only `simplex_tableau` and `revised_simplex_tableau` on continuous LPs run on the GPU engine (got algo `" << algo << "`)\n";
     std::cout << "Error\n";
     return 2;
   }
@@ -70,11 +71,27 @@ int main(int argc, char** argv) {
   lp_model.SetPivotingStrategy(strategy);
   lp_model.ToStandardForm();
   lp_model.ToSlackForm();
-  lp_model.ToTableau();
-  const Result result = lp_model.TableauSimplexSolve();
+  Result result = ERROR;
+  Num optimum;
+  std::map<Variable, Num> solution;
+  if (revised) {   // reference solver.cc:135-145
+    lp_model.ToTableau(COLUMN_ONLY);
+    result = lp_model.TableauRevisedSimplexSolve();
+    if (result == SOLVED) {
+      optimum = lp_model.GetTableauRevisedSimplexOptimum();
+      solution = lp_model.GetTableauRevisedSimplexSolution();
+    }
+  } else {         // reference solver.cc:123-133
+    lp_model.ToTableau();
+    result = lp_model.TableauSimplexSolve();
+    if (result == SOLVED) {
+      optimum = lp_model.GetTableauSimplexOptimum();
+      solution = lp_model.GetTableauSimplexSolution();
+    }
+  }
   if (result == SOLVED) {
-    std::cout << lp_model.GetTableauSimplexOptimum().ToString() << "\n";
-    for (auto& entry : lp_model.GetTableauSimplexSolution()) std::cout << entry.first.ToString() << " = " << entry.second.ToString() << "\n";
+    std::cout << optimum.ToString() << "\n";
+    for (auto& entry : solution) std::cout << entry.first.ToString() << " = " << entry.second.ToString() << "\n";
   } else if (result == NOSOLUTION) {
     std::cout << "No Solution\n";
   } else if (result == UNBOUNDED) {

@@ -953,3 +953,5 @@ int lpamd_poll(lpamd_engine* e, int32_t* result) {
 }
 
 }  // extern "C"
+
+#include "lpamd_revised.hip.h"

@@ -1,0 +1,493 @@
+// Host side of the lpamd_rev_* entry points of include/lpamd.h: the revised simplex
+// on the tableau (reference lp_revised_simplex_tableau.cc) with the tableau, the
+// basis inverse and all vectors resident on one GPU.  Included at the end of
+// lpamd_engine.hip (one translation unit, shared error handling).
+#include "lpamd_revised_kernels.hip.h"
+
+struct lpamd_rev_engine {
+  RevShape sh{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  // device memory
+  double* Trm = nullptr;
+  double* Binv = nullptr;
+  double* BinvT = nullptr;
+  double* obj = nullptr;
+  double* cost = nullptr;
+  uint8_t* is_basic = nullptr;
+  uint8_t* negate = nullptr;
+  int64_t* basis = nullptr;
+  int64_t* rows = nullptr;      // row of the single non-zero of every initial basis column
+  double* xB = nullptr;
+  double* cB = nullptr;
+  double* pvec = nullptr;
+  double* mu = nullptr;
+  double* colbuf = nullptr;
+  double* scaled = nullptr;
+  RevState* st = nullptr;
+  int64_t* trace = nullptr;
+  int64_t trace_cap = 0;
+  // host mirrors
+  RevState h_st{};
+  std::vector<double> h_obj;    // W entries, the objective row as the reference holds it at this point
+  std::vector<double> h_rhs;    // m entries, the right-hand side at upload time
+  bool opt_reverted = false;
+  bool loaded = false, started = false, finished = false;
+  int32_t final_result = LPAMD_ERROR;
+  double optimum = 0.0;
+  int colsum_unroll = 16;
+};
+
+namespace {
+
+#define CHECK_REV(h)                                                     \
+  do {                                                                   \
+    if (!(h)) return set_err(LPAMD_E_ARG, "null revised-simplex engine"); \
+    HIP_TRY(hipSetDevice((h)->device));                                  \
+  } while (0)
+
+void rev_free(lpamd_rev_engine* h) {
+  void* ptrs[] = {h->Trm, h->Binv, h->BinvT, h->obj, h->cost, h->is_basic, h->negate, h->basis, h->rows, h->xB,
+                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->st, h->trace};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  h->Trm = h->Binv = h->BinvT = h->obj = h->cost = h->xB = h->cB = h->pvec = h->mu = h->colbuf = h->scaled = nullptr;
+  h->is_basic = h->negate = nullptr;
+  h->basis = h->rows = h->trace = nullptr;
+  h->st = nullptr;
+  h->trace_cap = 0;
+}
+
+// Device buffers for W columns; everything is zero-filled.
+int rev_allocate(lpamd_rev_engine* h, int64_t W) {
+  rev_free(h);
+  RevShape& sh = h->sh;
+  sh.W = W;
+  sh.ldw = round_up(W, 64);
+  sh.ldb = round_up(sh.m, 64);
+  const size_t tbytes = sizeof(double) * (size_t)sh.m * sh.ldw, bbytes = sizeof(double) * (size_t)sh.m * sh.ldb;
+  hipError_t err = hipMalloc(&h->Trm, tbytes);
+  if (err == hipSuccess) err = hipMalloc(&h->Binv, bbytes);
+  if (err == hipSuccess) err = hipMalloc(&h->BinvT, bbytes);
+  if (err != hipSuccess)
+    return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB (tableau) + 2 x %.2f GB (basis inverse) failed: %s", tbytes / 1e9,
+                   bbytes / 1e9, hipGetErrorString(err));
+  HIP_TRY(hipMalloc(&h->obj, sizeof(double) * sh.ldw));
+  HIP_TRY(hipMalloc(&h->cost, sizeof(double) * sh.ldw));
+  HIP_TRY(hipMalloc(&h->is_basic, sh.ldw));
+  HIP_TRY(hipMalloc(&h->negate, sh.ldb));
+  HIP_TRY(hipMalloc(&h->basis, sizeof(int64_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->rows, sizeof(int64_t) * sh.ldb));
+  double** vecs[] = {&h->xB, &h->cB, &h->pvec, &h->mu, &h->colbuf, &h->scaled};
+  for (double** v : vecs) {
+    HIP_TRY(hipMalloc(v, sizeof(double) * sh.ldb));
+    HIP_TRY(hipMemsetAsync(*v, 0, sizeof(double) * sh.ldb, h->stream));
+  }
+  HIP_TRY(hipMalloc(&h->st, sizeof(RevState)));
+  HIP_TRY(hipMemsetAsync(h->Trm, 0, tbytes, h->stream));
+  HIP_TRY(hipMemsetAsync(h->obj, 0, sizeof(double) * sh.ldw, h->stream));
+  HIP_TRY(hipMemsetAsync(h->cost, 0, sizeof(double) * sh.ldw, h->stream));
+  HIP_TRY(hipMemsetAsync(h->is_basic, 0, sh.ldw, h->stream));
+  HIP_TRY(hipMemsetAsync(h->negate, 0, sh.ldb, h->stream));
+  HIP_TRY(hipMemsetAsync(h->st, 0, sizeof(RevState), h->stream));
+  h->trace_cap = 4096;
+  HIP_TRY(hipMalloc(&h->trace, sizeof(int64_t) * 2 * h->trace_cap));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memset(&h->h_st, 0, sizeof(RevState));
+  h->h_st.max_iter = std::numeric_limits<int64_t>::max();
+  h->started = h->finished = false;
+  return LPAMD_OK;
+}
+
+int rev_ensure_trace(lpamd_rev_engine* h, int64_t need) {
+  if (need <= h->trace_cap) return LPAMD_OK;
+  int64_t cap = h->trace_cap;
+  while (cap < need) cap *= 2;
+  int64_t* nt = nullptr;
+  HIP_TRY(hipMalloc(&nt, sizeof(int64_t) * 2 * cap));
+  HIP_TRY(hipMemcpyAsync(nt, h->trace, sizeof(int64_t) * 2 * h->trace_cap, hipMemcpyDeviceToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipFree(h->trace));
+  h->trace = nt;
+  h->trace_cap = cap;
+  return LPAMD_OK;
+}
+
+int rev_pull(lpamd_rev_engine* h) {
+  HIP_TRY(hipMemcpyAsync(&h->h_st, h->st, sizeof(RevState), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LPAMD_OK;
+}
+int rev_push(lpamd_rev_engine* h) {
+  HIP_TRY(hipMemcpyAsync(h->st, &h->h_st, sizeof(RevState), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LPAMD_OK;
+}
+int rev_upload_obj(lpamd_rev_engine* h) {
+  HIP_TRY(hipMemcpyAsync(h->obj, h->h_obj.data(), sizeof(double) * h->sh.W, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LPAMD_OK;
+}
+
+// out[0..ncols) = sum_r coef[r] * M[r][.] (+ base with the zero drop when cost is set)
+int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, int64_t ncols, const double* coef,
+               const double* base, double* out) {
+  // Two columns per lane once that still leaves two wavefronts per CU; the sum itself is
+  // sequential per lane, so the number of loads in flight is what hides the HBM latency.
+  const bool vec2 = ncols >= 2 * 64 * 512;
+  const int64_t per_block = (int64_t)kRevThreads * (vec2 ? 2 : 1);
+  const dim3 grid((unsigned)((ncols + per_block - 1) / per_block)), block(kRevThreads);
+  if (base) {
+    if (vec2) hipLaunchKernelGGL((k_rev_colsum<2, 16, true>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
+    else hipLaunchKernelGGL((k_rev_colsum<1, 16, true>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
+  } else {
+    if (vec2) hipLaunchKernelGGL((k_rev_colsum<2, 16, false>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
+    else hipLaunchKernelGGL((k_rev_colsum<1, 16, false>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
+  }
+  return check_launch("k_rev_colsum");
+}
+
+int rev_enqueue_update(lpamd_rev_engine* h) {
+  const RevShape& sh = h->sh;
+  const int64_t gx = (sh.m + 2 * kRevThreads - 1) / (2 * kRevThreads);
+  // about 4096 workgroups per matrix, at least 16 rows each
+  int64_t gy = std::max<int64_t>(1, std::min<int64_t>(4096 / gx, (sh.m + 15) / 16));
+  gy = std::min<int64_t>(gy, 65535);
+  const int64_t rows_per_block = (sh.m + gy - 1) / gy;
+  gy = (sh.m + rows_per_block - 1) / rows_per_block;
+  hipLaunchKernelGGL((k_rev_update<8>), dim3((unsigned)gx, (unsigned)gy, 2), dim3(kRevThreads), 0, h->stream, h->st, sh, h->Binv,
+                     h->BinvT, h->mu, h->scaled, rows_per_block);
+  return check_launch("k_rev_update");
+}
+
+// B^-1 * colbuf, ratio test (or the forced leaving position), vector part of the pivot, rank-1 update.
+int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
+  const RevShape& sh = h->sh;
+  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, sh.m, h->colbuf, nullptr, h->mu));
+  hipLaunchKernelGGL(k_rev_select_leaving, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB,
+                     h->cB, h->obj, h->basis, h->is_basic, h->Binv, h->scaled, h->trace, h->trace_cap);
+  LP_TRY(check_launch("k_rev_select_leaving"));
+  return rev_enqueue_update(h);
+}
+
+// One iteration of the main loop (reference lp_revised_simplex_tableau.cc:235-299).
+int rev_enqueue_iteration(lpamd_rev_engine* h, int64_t ncols_active) {
+  const RevShape& sh = h->sh;
+  LP_TRY(rev_colsum(h, h->Binv, sh.ldb, sh.m, sh.m, h->cB, nullptr, h->pvec));
+  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost));
+  hipLaunchKernelGGL((k_rev_select_entering<false>), dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, sh, ncols_active, h->cost,
+                     h->is_basic, h->Trm, h->colbuf);
+  LP_TRY(check_launch("k_rev_select_entering"));
+  return rev_enqueue_pivot_tail(h, -1);
+}
+
+// Runs the device-resident loop until the status leaves RUNNING or `max_pivots`
+// (total count, < 0: none) is reached.
+int rev_main_loop(lpamd_rev_engine* h, int64_t ncols_active, int64_t max_pivots, int32_t* result) {
+  LP_TRY(rev_pull(h));
+  h->h_st.status = ST_RUNNING;
+  h->h_st.max_iter = max_pivots < 0 ? std::numeric_limits<int64_t>::max() : max_pivots;
+  LP_TRY(rev_push(h));
+  int64_t batch = 4;
+  for (;;) {
+    int64_t todo = batch;
+    if (max_pivots >= 0) todo = std::max<int64_t>(1, std::min<int64_t>(batch, max_pivots - h->h_st.iter + 1));
+    LP_TRY(rev_ensure_trace(h, h->h_st.iter + todo));
+    const int64_t before = h->h_st.iter;
+    for (int64_t k = 0; k < todo; k++) LP_TRY(rev_enqueue_iteration(h, ncols_active));
+    LP_TRY(rev_pull(h));
+    if (h->h_st.status != ST_RUNNING) break;
+    if (h->h_st.iter == before) {
+      h->h_st.status = ST_ERROR;
+      set_err(LPAMD_E_STATE, "revised simplex loop made no progress");
+      break;
+    }
+    batch = std::min<int64_t>(batch * 2, 256);
+  }
+  *result = status_to_result(h->h_st.status);
+  return LPAMD_OK;
+}
+
+int rev_read_basis_solution(lpamd_rev_engine* h, std::vector<int64_t>& basis, std::vector<double>& xB) {
+  basis.resize(h->sh.m);
+  xB.resize(h->sh.m);
+  HIP_TRY(hipMemcpyAsync(basis.data(), h->basis, sizeof(int64_t) * h->sh.m, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(xB.data(), h->xB, sizeof(double) * h->sh.m, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LPAMD_OK;
+}
+
+// reference lp_revised_simplex_tableau.cc:253-257
+int rev_compute_optimum(lpamd_rev_engine* h) {
+  std::vector<int64_t> basis;
+  std::vector<double> xB;
+  LP_TRY(rev_read_basis_solution(h, basis, xB));
+  double v = h->h_obj[h->sh.N];
+  for (int64_t i = 0; i < h->sh.m; i++) v += h->h_obj[basis[i]] * xB[i];
+  if (h->opt_reverted) v *= -1;
+  h->optimum = v;
+  return LPAMD_OK;
+}
+
+int rev_init_basis(lpamd_rev_engine* h) {
+  const RevShape& sh = h->sh;
+  HIP_TRY(hipMemsetAsync(h->Binv, 0, sizeof(double) * (size_t)sh.m * sh.ldb, h->stream));
+  HIP_TRY(hipMemsetAsync(h->BinvT, 0, sizeof(double) * (size_t)sh.m * sh.ldb, h->stream));
+  hipLaunchKernelGGL(k_rev_init_basis, dim3((unsigned)((sh.m + 255) / 256)), dim3(256), 0, h->stream, sh, h->basis, h->rows, h->Trm,
+                     h->obj, h->Binv, h->BinvT, h->xB, h->cB);
+  return check_launch("k_rev_init_basis");
+}
+
+// Feasibility phase (reference lp_revised_simplex_tableau.cc:92-197).
+int rev_phase1(lpamd_rev_engine* h, int64_t max_pivots, int32_t* result) {
+  const RevShape& sh = h->sh;
+  const int64_t m = sh.m, N = sh.N, W0 = N + 1;
+  if (sh.W < W0 + m) return set_err(LPAMD_E_STATE, "the feasibility phase needs the artificial block (upload decides it from the right-hand side)");
+  // rows with a negative right-hand side are negated (:95-114)
+  std::vector<uint8_t> neg(m, 0);
+  for (int64_t i = 0; i < m; i++) neg[i] = h_is_neg(h->h_rhs[i]) ? 1 : 0;
+  HIP_TRY(hipMemcpyAsync(h->negate, neg.data(), m, hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_rev_negate_rows, dim3((unsigned)m, (unsigned)((W0 + 255) / 256)), dim3(256), 0, h->stream, sh, h->negate, h->Trm);
+  LP_TRY(check_launch("k_rev_negate_rows"));
+  const std::vector<double> raw_obj = h->h_obj;
+  const bool raw_reverted = h->opt_reverted;
+  // auxiliary problem: one artificial column per row, objective -sum(artificials) (:116-137),
+  // negated once more by the nested solve (:201-202)
+  std::vector<uint8_t> basic(sh.W, 0);
+  std::vector<int64_t> basis(m), rows(m);
+  for (int64_t j = 0; j < sh.W; j++) h->h_obj[j] = 0.0;
+  for (int64_t i = 0; i < m; i++) {
+    h->h_obj[W0 + i] = -1.0;
+    basic[W0 + i] = 1;
+    basis[i] = W0 + i;
+    rows[i] = i;
+  }
+  for (int64_t j = 0; j < sh.W; j++) h->h_obj[j] = h->h_obj[j] * -1.0;
+  h->opt_reverted = !h->opt_reverted;
+  hipLaunchKernelGGL(k_rev_fill_artificials, dim3((unsigned)m, (unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, sh, h->Trm);
+  LP_TRY(check_launch("k_rev_fill_artificials"));
+  HIP_TRY(hipMemcpyAsync(h->is_basic, basic.data(), sh.W, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->basis, basis.data(), sizeof(int64_t) * m, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->rows, rows.data(), sizeof(int64_t) * m, hipMemcpyHostToDevice, h->stream));
+  LP_TRY(rev_upload_obj(h));   // synchronises: the host vectors above may go out of scope
+  LP_TRY(rev_init_basis(h));
+  int32_t r1 = LPAMD_ERROR;
+  LP_TRY(rev_main_loop(h, sh.W, max_pivots, &r1));
+  if (r1 == LPAMD_LIMIT) { *result = LPAMD_LIMIT; return LPAMD_OK; }
+  if (r1 != LPAMD_SOLVED) { *result = LPAMD_ERROR; return LPAMD_OK; }        // :140, a live assert upstream
+  LP_TRY(rev_compute_optimum(h));
+  if (!h_is_zero(h->optimum)) { *result = LPAMD_NOSOLUTION; return LPAMD_OK; }   // :142
+  // artificial variables still basic are pivoted out on the first structural column
+  // with a non-zero entry in their row of B^-1 * A (:145-170)
+  std::vector<double> xB;
+  LP_TRY(rev_read_basis_solution(h, basis, xB));
+  h->h_st.status = ST_RUNNING;
+  h->h_st.max_iter = std::numeric_limits<int64_t>::max();
+  LP_TRY(rev_push(h));
+  for (int64_t i = 0; i < m; i++) {
+    if (basis[i] < N) continue;
+    LP_TRY(rev_ensure_trace(h, h->h_st.iter + 1));
+    LP_TRY(rev_colsum(h, h->Trm, sh.ldw, m, W0, h->Binv + i * sh.ldb, nullptr, h->cost));
+    hipLaunchKernelGGL((k_rev_select_entering<true>), dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, sh, W0, h->cost, h->is_basic,
+                       h->Trm, h->colbuf);
+    LP_TRY(check_launch("k_rev_select_entering"));
+    LP_TRY(rev_enqueue_pivot_tail(h, i));
+    LP_TRY(rev_pull(h));
+    if (h->h_st.status != ST_RUNNING) { *result = LPAMD_ERROR; return LPAMD_OK; }   // :165, a live assert upstream
+    basis[i] = h->h_st.e;
+  }
+  // back to the real objective (:171-195); the artificial block is simply left out of the pricing from here on
+  h->h_obj = raw_obj;
+  h->opt_reverted = raw_reverted;
+  LP_TRY(rev_upload_obj(h));
+  hipLaunchKernelGGL(k_rev_gather_basis_cost, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, m, h->basis, h->obj, h->cB);
+  LP_TRY(check_launch("k_rev_gather_basis_cost"));
+  *result = LPAMD_SOLVED;
+  return LPAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_stream) {
+  if (!out) return set_err(LPAMD_E_ARG, "out is null");
+  *out = nullptr;
+  if (m <= 0 || N <= 0) return set_err(LPAMD_E_ARG, "bad shape m=%lld N=%lld", (long long)m, (long long)N);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
+  lpamd_rev_engine* h = new lpamd_rev_engine();
+  h->sh.m = m;
+  h->sh.N = N;
+  if (hipGetDevice(&h->device) != hipSuccess) { delete h; return set_err(LPAMD_E_HIP, "hipGetDevice failed"); }
+  if (hip_stream) {
+    h->stream = (hipStream_t)hip_stream;
+  } else if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return set_err(LPAMD_E_HIP, "hipStreamCreate failed");
+  } else {
+    h->own_stream = true;
+  }
+  *out = h;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_destroy(lpamd_rev_engine* h) {
+  if (!h) return LPAMD_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  rev_free(h);
+  if (h->own_stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_upload(lpamd_rev_engine* h, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic, int32_t opt_reverted) {
+  CHECK_REV(h);
+  const int64_t m = h->sh.m, N = h->sh.N, W0 = N + 1;
+  if (!T || !obj || !is_basic || ld < m) return set_err(LPAMD_E_ARG, "rev_upload: null buffer or ld < m");
+  bool need_init = false;
+  for (int64_t i = 0; i < m; i++) need_init |= h_is_neg(T[N * ld + i]);   // reference :8-16
+  // initial basis: the basic columns in index order, each with its first non-zero row (:216-232)
+  std::vector<int64_t> basis, rows;
+  for (int64_t j = 0; j < N; j++) {
+    if (!is_basic[j]) continue;
+    int64_t r = -1;
+    for (int64_t i = 0; i < m; i++)
+      if (!h_is_zero(T[j * ld + i])) { r = i; break; }
+    basis.push_back(j);
+    rows.push_back(r);
+  }
+  if ((int64_t)basis.size() != m)
+    return set_err(LPAMD_E_ARG, "rev_upload: %lld basic columns for %lld rows", (long long)basis.size(), (long long)m);
+  LP_TRY(rev_allocate(h, need_init ? W0 + m : W0));
+  const RevShape& sh = h->sh;
+  std::vector<double> rm((size_t)m * sh.ldw, 0.0);
+  for (int64_t j = 0; j < W0; j++)
+    for (int64_t i = 0; i < m; i++) rm[(size_t)i * sh.ldw + j] = T[j * ld + i];
+  std::vector<uint8_t> basic(sh.W, 0);
+  for (int64_t j = 0; j < N; j++) basic[j] = is_basic[j] ? 1 : 0;
+  h->h_obj.assign(sh.W, 0.0);
+  for (int64_t j = 0; j < W0; j++) h->h_obj[j] = obj[j];
+  h->h_rhs.assign(T + N * ld, T + N * ld + m);
+  h->opt_reverted = opt_reverted != 0;
+  HIP_TRY(hipMemcpyAsync(h->Trm, rm.data(), sizeof(double) * rm.size(), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->is_basic, basic.data(), sh.W, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->basis, basis.data(), sizeof(int64_t) * m, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->rows, rows.data(), sizeof(int64_t) * m, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->loaded = true;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_fill_synthetic(lpamd_rev_engine* h, int64_t n_struct, uint64_t seed) {
+  CHECK_REV(h);
+  const int64_t m = h->sh.m, N = h->sh.N;
+  if (n_struct <= 0 || n_struct + m != N) return set_err(LPAMD_E_ARG, "rev_fill_synthetic: N must equal n_struct + m");
+  LP_TRY(rev_allocate(h, N + 1));
+  const RevShape& sh = h->sh;
+  hipLaunchKernelGGL(k_rev_fill_synthetic, dim3((unsigned)m, (unsigned)((sh.ldw + 255) / 256)), dim3(256), 0, h->stream, sh, h->Trm,
+                     h->is_basic, h->basis, h->rows, n_struct, seed);
+  LP_TRY(check_launch("k_rev_fill_synthetic"));
+  h->h_obj.assign(sh.W, 0.0);
+  for (int64_t j = 0; j <= N; j++) h->h_obj[j] = synth_entry(seed, m, n_struct, m, j);
+  h->h_rhs.resize(m);
+  for (int64_t i = 0; i < m; i++) h->h_rhs[i] = synth_entry(seed, m, n_struct, i, N);
+  h->opt_reverted = false;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  h->loaded = true;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_solve(lpamd_rev_engine* h, int64_t max_pivots, int32_t* result, int64_t* n_pivots) {
+  CHECK_REV(h);
+  if (!h->loaded) return set_err(LPAMD_E_STATE, "no tableau uploaded yet");
+  if (!result) return set_err(LPAMD_E_ARG, "result is null");
+  const RevShape& sh = h->sh;
+  const int64_t W0 = sh.N + 1;
+  int32_t res = LPAMD_ERROR;
+  if (h->finished) return set_err(LPAMD_E_STATE, "rev_solve: this tableau has been solved already (upload again)");
+  if (!h->started) {
+    h->started = true;
+    for (int64_t j = 0; j < W0; j++) h->h_obj[j] = h->h_obj[j] * -1.0;   // reference :201
+    h->opt_reverted = !h->opt_reverted;                                   // :202
+    bool need_init = false;
+    for (int64_t i = 0; i < sh.m; i++) need_init |= h_is_neg(h->h_rhs[i]);
+    if (need_init) {
+      LP_TRY(rev_phase1(h, max_pivots, &res));
+      if (res != LPAMD_SOLVED) {
+        h->finished = true;
+        h->final_result = res;
+        *result = res;
+        if (n_pivots) *n_pivots = h->h_st.iter;
+        return LPAMD_OK;
+      }
+    } else {
+      LP_TRY(rev_upload_obj(h));
+      LP_TRY(rev_init_basis(h));
+    }
+  }
+  LP_TRY(rev_main_loop(h, W0, max_pivots, &res));
+  if (res == LPAMD_SOLVED) LP_TRY(rev_compute_optimum(h));
+  if (res != LPAMD_LIMIT) h->finished = true;   // a budgeted run may be continued with a larger budget
+  h->final_result = res;
+  *result = res;
+  if (n_pivots) *n_pivots = h->h_st.iter;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_optimum(lpamd_rev_engine* h, double* out) {
+  CHECK_REV(h);
+  if (!h->finished || h->final_result != LPAMD_SOLVED) return set_err(LPAMD_E_STATE, "rev_optimum: not solved");
+  *out = h->optimum;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_column_values(lpamd_rev_engine* h, double* x) {
+  CHECK_REV(h);
+  if (!h->started) return set_err(LPAMD_E_STATE, "rev_column_values: rev_solve has not run");
+  std::vector<int64_t> basis;
+  std::vector<double> xB;
+  LP_TRY(rev_read_basis_solution(h, basis, xB));
+  for (int64_t j = 0; j < h->sh.N + 2; j++) x[j] = 0.0;
+  for (int64_t i = 0; i < h->sh.m; i++)
+    if (basis[i] >= 0 && basis[i] < h->sh.N) x[basis[i]] = xB[i];
+  return LPAMD_OK;
+}
+
+int lpamd_rev_pivot_count(lpamd_rev_engine* h, int64_t* n) {
+  CHECK_REV(h);
+  *n = h->h_st.iter;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_trace(lpamd_rev_engine* h, int64_t* te, int64_t* tl, int64_t cap, int64_t* n) {
+  CHECK_REV(h);
+  if (!h->started) { *n = 0; return LPAMD_OK; }
+  const int64_t k = std::min<int64_t>({cap, h->h_st.iter, h->trace_cap});
+  std::vector<int64_t> t(2 * std::max<int64_t>(k, 1));
+  if (k > 0) {
+    HIP_TRY(hipMemcpyAsync(t.data(), h->trace, sizeof(int64_t) * 2 * k, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  for (int64_t i = 0; i < k; i++) { te[i] = t[2 * i]; tl[i] = t[2 * i + 1]; }
+  *n = k;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_read_state(lpamd_rev_engine* h, double* Binv, double* BinvT, double* xB, double* cB, int64_t* basis) {
+  CHECK_REV(h);
+  if (!h->started) return set_err(LPAMD_E_STATE, "rev_read_state: rev_solve has not run");
+  const RevShape& sh = h->sh;
+  const size_t row = sizeof(double) * sh.m;
+  if (Binv) HIP_TRY(hipMemcpy2DAsync(Binv, row, h->Binv, sizeof(double) * sh.ldb, row, sh.m, hipMemcpyDeviceToHost, h->stream));
+  if (BinvT) HIP_TRY(hipMemcpy2DAsync(BinvT, row, h->BinvT, sizeof(double) * sh.ldb, row, sh.m, hipMemcpyDeviceToHost, h->stream));
+  if (xB) HIP_TRY(hipMemcpyAsync(xB, h->xB, row, hipMemcpyDeviceToHost, h->stream));
+  if (cB) HIP_TRY(hipMemcpyAsync(cB, h->cB, row, hipMemcpyDeviceToHost, h->stream));
+  if (basis) HIP_TRY(hipMemcpyAsync(basis, h->basis, sizeof(int64_t) * sh.m, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  return LPAMD_OK;
+}
+
+}  // extern "C"

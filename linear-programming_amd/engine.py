@@ -3,7 +3,9 @@
 Mirrors the tableau part of the reference's LPModel surface (reference
 lp.h:64-106): ToTableau -> TableauEngine.upload, TableauPivot -> pivot,
 TableauSimplexInitialize -> phase1, TableauSimplexSolve -> solve,
-GetTableauSimplexOptimum/Solution -> objective_constant / column_values.
+GetTableauSimplexOptimum/Solution -> objective_constant / column_values;
+TableauRevisedSimplexSolve and its getters (reference lp.h:128-134) ->
+RevisedTableauEngine.
 """
 import ctypes
 import os
@@ -75,6 +77,16 @@ def library():
         "lpamd_set_pivot_budget": (ctypes.c_int, [vp, i64]),
         "lpamd_apply_pivot": (ctypes.c_int, [vp, i32, i64, i64, vp]),
         "lpamd_poll": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_rev_create": (ctypes.c_int, [P(vp), i64, i64, vp]),
+        "lpamd_rev_destroy": (ctypes.c_int, [vp]),
+        "lpamd_rev_upload": (ctypes.c_int, [vp, vp, i64, vp, vp, i32]),
+        "lpamd_rev_fill_synthetic": (ctypes.c_int, [vp, i64, u64]),
+        "lpamd_rev_solve": (ctypes.c_int, [vp, i64, P(i32), P(i64)]),
+        "lpamd_rev_optimum": (ctypes.c_int, [vp, P(ctypes.c_double)]),
+        "lpamd_rev_column_values": (ctypes.c_int, [vp, vp]),
+        "lpamd_rev_pivot_count": (ctypes.c_int, [vp, P(i64)]),
+        "lpamd_rev_trace": (ctypes.c_int, [vp, vp, vp, i64, P(i64)]),
+        "lpamd_rev_read_state": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)   # AttributeError here = header and library disagree
@@ -263,3 +275,74 @@ class TableauEngine:
 
     def exchange_doubles(self):
         return int(self.L.lpamd_exchange_bytes(self.m)) // 8
+
+
+class RevisedTableauEngine:
+    """Revised simplex on the tableau, resident on the current HIP device
+    (reference lp_revised_simplex_tableau.cc; one method per lpamd_rev_* entry point)."""
+
+    def __init__(self, m, N, stream=None):
+        self.L = library()
+        self.m, self.N = int(m), int(N)
+        self.h = ctypes.c_void_p()
+        _ck(self.L.lpamd_rev_create(ctypes.byref(self.h), self.m, self.N, ctypes.c_void_p(stream) if stream else None))
+
+    def close(self):
+        if self.h:
+            self.L.lpamd_rev_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, T, obj, is_basic, opt_reverted):
+        T = np.asfortranarray(T, dtype=np.float64)
+        assert T.shape[0] == self.m and T.shape[1] >= self.N + 1, (T.shape, self.m, self.N)
+        obj = np.ascontiguousarray(obj, dtype=np.float64)
+        is_basic = np.ascontiguousarray(is_basic, dtype=np.uint8)
+        assert obj.shape[0] >= self.N + 1 and is_basic.shape[0] >= self.N
+        _ck(self.L.lpamd_rev_upload(self.h, T.ctypes.data, max(T.strides[1] // 8, self.m), obj.ctypes.data, is_basic.ctypes.data,
+                                    1 if opt_reverted else 0))
+
+    def fill_synthetic(self, n_struct, seed):
+        _ck(self.L.lpamd_rev_fill_synthetic(self.h, int(n_struct), int(seed)))
+
+    def solve(self, max_pivots=-1):
+        res, n = ctypes.c_int32(), ctypes.c_int64()
+        _ck(self.L.lpamd_rev_solve(self.h, int(max_pivots), ctypes.byref(res), ctypes.byref(n)))
+        return res.value, n.value
+
+    def optimum(self):
+        v = ctypes.c_double()
+        _ck(self.L.lpamd_rev_optimum(self.h, ctypes.byref(v)))
+        return v.value
+
+    def column_values(self):
+        x = np.zeros(self.N + 2, dtype=np.float64)
+        _ck(self.L.lpamd_rev_column_values(self.h, x.ctypes.data))
+        return x
+
+    def pivot_count(self):
+        n = ctypes.c_int64()
+        _ck(self.L.lpamd_rev_pivot_count(self.h, ctypes.byref(n)))
+        return n.value
+
+    def trace(self):
+        n = self.pivot_count()
+        e = np.zeros(max(n, 1), dtype=np.int64)
+        l = np.zeros(max(n, 1), dtype=np.int64)
+        got = ctypes.c_int64()
+        _ck(self.L.lpamd_rev_trace(self.h, e.ctypes.data, l.ctypes.data, n, ctypes.byref(got)))
+        return list(zip(e[:got.value].tolist(), l[:got.value].tolist()))
+
+    def read_state(self, matrices=True):
+        m = self.m
+        Binv = np.zeros((m, m), dtype=np.float64) if matrices else None
+        BinvT = np.zeros((m, m), dtype=np.float64) if matrices else None
+        xB, cB, basis = np.zeros(m), np.zeros(m), np.zeros(m, dtype=np.int64)
+        _ck(self.L.lpamd_rev_read_state(self.h, Binv.ctypes.data if matrices else None, BinvT.ctypes.data if matrices else None,
+                                        xB.ctypes.data, cB.ctypes.data, basis.ctypes.data))
+        return Binv, BinvT, xB, cB, basis

@@ -6,7 +6,7 @@ import subprocess
 
 import pytest
 
-from cases import GOLDEN, ROOT, all_cases, case_golden
+from cases import GOLDEN, REVISED_CASES, ROOT, all_cases, case_golden, revised_golden
 from oracle import lp_oracle as lo
 from cases import case_text
 
@@ -48,4 +48,28 @@ def test_solver_cli_texts_for_unbounded_and_infeasible(tmp_path):
     p = tmp_path / "inf.txt"
     p.write_text("max x1\nst\nx1 <= 1\nx1 >= 2\nx1 >= 0\n")
     out = subprocess.run([os.path.join(BIN, "solver"), str(p), "simplex_tableau", "MAX_REDUCTION"], capture_output=True, text=True)
+    assert out.stdout == "No Solution\n"
+
+
+@pytest.mark.parametrize("name,golden", REVISED_CASES)
+def test_solver_cli_revised_matches_reference_golden(name, golden):
+    """`solver <file> revised_simplex_tableau` (reference CMakeLists.txt:105-114, 138-144)."""
+    out = subprocess.run([os.path.join(BIN, "solver"), _path(name), "revised_simplex_tableau", "max_cost", "--trace"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.rstrip("\n") == revised_golden(golden).rstrip("\n")
+    _, rt = lo.revised_from_text(case_text(name))
+    rt.solve()
+    got = [tuple(map(int, l.split()[1:])) for l in out.stderr.splitlines() if l.startswith("pivot ")]
+    assert got == rt.trace()
+
+
+def test_solver_cli_revised_texts_for_unbounded_and_infeasible(tmp_path):
+    p = tmp_path / "unb.txt"
+    p.write_text("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n")
+    out = subprocess.run([os.path.join(BIN, "solver"), str(p), "revised_simplex_tableau"], capture_output=True, text=True)
+    assert out.stdout == "Unbounded\n"
+    p = tmp_path / "inf.txt"
+    p.write_text("max x1\nst\nx1 <= 1\nx1 >= 2\nx1 >= 0\n")
+    out = subprocess.run([os.path.join(BIN, "solver"), str(p), "revised_simplex_tableau"], capture_output=True, text=True)
     assert out.stdout == "No Solution\n"
