@@ -198,3 +198,4 @@ def test_rccl_collectives_single_rank(lpamd, exchange):
         assert np.array_equal(bits(T), bits(dt.T)) and np.array_equal(bits(obj), bits(dt.obj))
     finally:
         dist.destroy_process_group()
+
