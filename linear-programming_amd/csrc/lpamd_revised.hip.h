@@ -11,8 +11,7 @@ struct lpamd_rev_engine {
   bool own_stream = false;
   // device memory
   double* Trm = nullptr;
-  double* Binv = nullptr;
-  double* BinvT = nullptr;
+  double* BinvT = nullptr;      // basis inverse, stored transposed
   double* obj = nullptr;
   double* cost = nullptr;
   uint8_t* is_basic = nullptr;
@@ -25,6 +24,9 @@ struct lpamd_rev_engine {
   double* mu = nullptr;
   double* colbuf = nullptr;
   double* scaled = nullptr;
+  int32_t* idx_col = nullptr;   // rows of the non-zero entries of colbuf
+  int32_t* idx_upd = nullptr;   // rows of BinvT the pending update visits
+  uint8_t* touched = nullptr;   // one byte per row of BinvT: the pending update visits it
   RevState* st = nullptr;
   int64_t* trace = nullptr;
   int64_t trace_cap = 0;
@@ -36,7 +38,12 @@ struct lpamd_rev_engine {
   bool loaded = false, started = false, finished = false;
   int32_t final_result = LPAMD_ERROR;
   double optimum = 0.0;
-  int colsum_unroll = 16;
+  // kernel shape overrides (0 = by size), for tests and tuning: LPAMD_REV_COLSUM_VEC=1|2,
+  // LPAMD_REV_ROWDOT_ROWS=16|64, LPAMD_REV_UPDATE_UNROLL=4|16
+  // LPAMD_REV_SPLIT=0|1: strided gathers inside the single-workgroup selection kernels / as
+  // chip-wide kernels of their own (default: by size)
+  int force_vec = 0, force_rowdot_rows = 0, force_update_unroll = 0, force_split = -1;
+  bool split() const { return force_split >= 0 ? force_split != 0 : sh.m > 8192; }
 };
 
 namespace {
@@ -48,13 +55,14 @@ namespace {
   } while (0)
 
 void rev_free(lpamd_rev_engine* h) {
-  void* ptrs[] = {h->Trm, h->Binv, h->BinvT, h->obj, h->cost, h->is_basic, h->negate, h->basis, h->rows, h->xB,
-                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->st, h->trace};
+  void* ptrs[] = {h->Trm, h->BinvT, h->obj, h->cost, h->is_basic, h->negate, h->basis, h->rows, h->xB,
+                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_col, h->idx_upd, h->touched, h->st, h->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
-  h->Trm = h->Binv = h->BinvT = h->obj = h->cost = h->xB = h->cB = h->pvec = h->mu = h->colbuf = h->scaled = nullptr;
-  h->is_basic = h->negate = nullptr;
+  h->Trm = h->BinvT = h->obj = h->cost = h->xB = h->cB = h->pvec = h->mu = h->colbuf = h->scaled = nullptr;
+  h->is_basic = h->negate = h->touched = nullptr;
   h->basis = h->rows = h->trace = nullptr;
+  h->idx_col = h->idx_upd = nullptr;
   h->st = nullptr;
   h->trace_cap = 0;
 }
@@ -68,10 +76,9 @@ int rev_allocate(lpamd_rev_engine* h, int64_t W) {
   sh.ldb = round_up(sh.m, 64);
   const size_t tbytes = sizeof(double) * (size_t)sh.m * sh.ldw, bbytes = sizeof(double) * (size_t)sh.m * sh.ldb;
   hipError_t err = hipMalloc(&h->Trm, tbytes);
-  if (err == hipSuccess) err = hipMalloc(&h->Binv, bbytes);
   if (err == hipSuccess) err = hipMalloc(&h->BinvT, bbytes);
   if (err != hipSuccess)
-    return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB (tableau) + 2 x %.2f GB (basis inverse) failed: %s", tbytes / 1e9,
+    return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB (tableau) + %.2f GB (basis inverse) failed: %s", tbytes / 1e9,
                    bbytes / 1e9, hipGetErrorString(err));
   HIP_TRY(hipMalloc(&h->obj, sizeof(double) * sh.ldw));
   HIP_TRY(hipMalloc(&h->cost, sizeof(double) * sh.ldw));
@@ -79,6 +86,9 @@ int rev_allocate(lpamd_rev_engine* h, int64_t W) {
   HIP_TRY(hipMalloc(&h->negate, sh.ldb));
   HIP_TRY(hipMalloc(&h->basis, sizeof(int64_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->rows, sizeof(int64_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->idx_col, sizeof(int32_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->idx_upd, sizeof(int32_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->touched, sh.ldb));
   double** vecs[] = {&h->xB, &h->cB, &h->pvec, &h->mu, &h->colbuf, &h->scaled};
   for (double** v : vecs) {
     HIP_TRY(hipMalloc(v, sizeof(double) * sh.ldb));
@@ -130,55 +140,117 @@ int rev_upload_obj(lpamd_rev_engine* h) {
   return LPAMD_OK;
 }
 
-// out[0..ncols) = sum_r coef[r] * M[r][.] (+ base with the zero drop when cost is set)
-int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, int64_t ncols, const double* coef,
-               const double* base, double* out) {
-  // Two columns per lane once that still leaves two wavefronts per CU; the sum itself is
-  // sequential per lane, so the number of loads in flight is what hides the HBM latency.
-  const bool vec2 = ncols >= 2 * 64 * 512;
-  const int64_t per_block = (int64_t)kRevThreads * (vec2 ? 2 : 1);
-  const dim3 grid((unsigned)((ncols + per_block - 1) / per_block)), block(kRevThreads);
+// out[0..ncols) = sum over rows of coef[r] * M[r][.] (+ base with the zero drop when it is given);
+// idx/count (device) restrict the sum to the listed rows.
+int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, const int32_t* idx, const int32_t* count,
+               int64_t ncols, const double* coef, const double* base, double* out) {
+  // Two columns (16 bytes) per lane once that still leaves a wavefront per CU: measured 5.3 vs
+  // 4.9 TB/s on the 32768-wide inverse.  The sum itself is sequential per lane, so the loads in
+  // flight are what hides the HBM latency.
+  const bool vec2 = h->force_vec ? h->force_vec == 2 : ncols >= 2 * 64 * 128;
+  // narrow outputs: one wavefront per workgroup, so that the lanes spread over all CUs
+  const int threads = ncols / (vec2 ? 2 : 1) >= 512 * kRevThreads ? kRevThreads : kWave;
+  const int64_t per_block = (int64_t)threads * (vec2 ? 2 : 1);
+  const dim3 grid((unsigned)((ncols + per_block - 1) / per_block)), block(threads);
+#define LPAMD_REV_COLSUM(V, U, C, I) \
+  hipLaunchKernelGGL((k_rev_colsum<V, U, C, I>), grid, block, 0, h->stream, h->st, M, ld, nrows, idx, count, ncols, coef, base, out)
+#define LPAMD_REV_COLSUM_I(V, U, C)                     \
+  do {                                                  \
+    if (idx) LPAMD_REV_COLSUM(V, U, C, true);           \
+    else LPAMD_REV_COLSUM(V, U, C, false);              \
+  } while (0)
+  // one column per lane leaves few lanes on narrow outputs: 32 row loads in flight instead of 16
+  const bool deep = !vec2 && nrows >= 8192;
   if (base) {
-    if (vec2) hipLaunchKernelGGL((k_rev_colsum<2, 16, true>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
-    else hipLaunchKernelGGL((k_rev_colsum<1, 16, true>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
+    if (vec2) LPAMD_REV_COLSUM_I(2, 16, true);
+    else if (deep) LPAMD_REV_COLSUM_I(1, 32, true);
+    else LPAMD_REV_COLSUM_I(1, 16, true);
   } else {
-    if (vec2) hipLaunchKernelGGL((k_rev_colsum<2, 16, false>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
-    else hipLaunchKernelGGL((k_rev_colsum<1, 16, false>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out);
+    if (vec2) LPAMD_REV_COLSUM_I(2, 16, false);
+    else if (deep) LPAMD_REV_COLSUM_I(1, 32, false);
+    else LPAMD_REV_COLSUM_I(1, 16, false);
   }
+#undef LPAMD_REV_COLSUM_I
+#undef LPAMD_REV_COLSUM
   return check_launch("k_rev_colsum");
+}
+
+// p = c_B^T * B^-1: a dot product along every row of the transposed inverse
+int rev_rowdot(lpamd_rev_engine* h) {
+  const RevShape& sh = h->sh;
+  // 64 rows per workgroup need m / 64 >= 256 workgroups to fill the chip; below that 16 rows
+  const bool rows64 = h->force_rowdot_rows ? h->force_rowdot_rows == 64 : sh.m >= 16384;
+  if (rows64)
+    hipLaunchKernelGGL((k_rev_rowdot<64>), dim3((unsigned)((sh.m + 63) / 64)), dim3(kRevThreads), 0, h->stream, h->st, h->BinvT, sh.ldb,
+                       sh.m, sh.m, h->cB, h->pvec);
+  else
+    hipLaunchKernelGGL((k_rev_rowdot<16>), dim3((unsigned)((sh.m + 15) / 16)), dim3(kRevThreads), 0, h->stream, h->st, h->BinvT, sh.ldb,
+                       sh.m, sh.m, h->cB, h->pvec);
+  return check_launch("k_rev_rowdot");
 }
 
 int rev_enqueue_update(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
-  const int64_t gx = (sh.m + 2 * kRevThreads - 1) / (2 * kRevThreads);
-  // about 4096 workgroups per matrix, at least 16 rows each
-  int64_t gy = std::max<int64_t>(1, std::min<int64_t>(4096 / gx, (sh.m + 15) / 16));
-  gy = std::min<int64_t>(gy, 65535);
-  const int64_t rows_per_block = (sh.m + gy - 1) / gy;
-  gy = (sh.m + rows_per_block - 1) / rows_per_block;
-  hipLaunchKernelGGL((k_rev_update<8>), dim3((unsigned)gx, (unsigned)gy, 2), dim3(kRevThreads), 0, h->stream, h->st, sh, h->Binv,
-                     h->BinvT, h->mu, h->scaled, rows_per_block);
+  const int grid = 4096;   // work items (listed row x run of vectors) are dealt round-robin
+  const bool unroll16 = h->force_update_unroll ? h->force_update_unroll == 16 : sh.ldb >= 8192;
+  if (unroll16)
+    hipLaunchKernelGGL((k_rev_update<16>), dim3(grid), dim3(kRevThreads), 0, h->stream, h->st, sh, h->BinvT, h->mu, h->scaled, h->idx_upd);
+  else
+    hipLaunchKernelGGL((k_rev_update<4>), dim3(grid), dim3(kRevThreads), 0, h->stream, h->st, sh, h->BinvT, h->mu, h->scaled, h->idx_upd);
   return check_launch("k_rev_update");
 }
 
-// B^-1 * colbuf, ratio test (or the forced leaving position), vector part of the pivot, rank-1 update.
+// Entering column (pricing, or the first column with a non-zero probe entry), its copy in
+// colbuf and the list of its non-zero rows.
+int rev_enqueue_entering(lpamd_rev_engine* h, bool first_nonzero, int64_t ncols_active) {
+  const RevShape& sh = h->sh;
+  const dim3 one(1), sel(kRevSelectThreads);
+#define LPAMD_REV_ENTER(F, G) \
+  hipLaunchKernelGGL((k_rev_select_entering<F, G>), one, sel, 0, h->stream, h->st, sh, ncols_active, h->cost, h->is_basic, h->Trm, h->colbuf, h->idx_col)
+  if (!h->split()) {
+    if (first_nonzero) LPAMD_REV_ENTER(true, true); else LPAMD_REV_ENTER(false, true);
+    return check_launch("k_rev_select_entering");
+  }
+  if (first_nonzero) LPAMD_REV_ENTER(true, false); else LPAMD_REV_ENTER(false, false);
+#undef LPAMD_REV_ENTER
+  LP_TRY(check_launch("k_rev_select_entering"));
+  hipLaunchKernelGGL(k_rev_gather_wide, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
+                     h->Trm, sh.ldw, sh.m, (int64_t)-1, h->colbuf);
+  LP_TRY(check_launch("k_rev_gather_wide"));
+  hipLaunchKernelGGL(k_rev_list_nonzero, one, sel, 0, h->stream, h->st, h->colbuf, sh.m, h->idx_col);
+  return check_launch("k_rev_list_nonzero");
+}
+
+// B^-1 * colbuf (over the listed non-zero rows of colbuf), ratio test (or the forced leaving
+// position), vector part of the pivot, rank-1 update.
 int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
   const RevShape& sh = h->sh;
-  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, sh.m, h->colbuf, nullptr, h->mu));
-  hipLaunchKernelGGL(k_rev_select_leaving, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB,
-                     h->cB, h->obj, h->basis, h->is_basic, h->Binv, h->scaled, h->trace, h->trace_cap);
-  LP_TRY(check_launch("k_rev_select_leaving"));
+  const dim3 one(1), sel(kRevSelectThreads);
+  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, h->idx_col, &h->st->n_col, sh.m, h->colbuf, nullptr, h->mu));
+  if (!h->split()) {
+    hipLaunchKernelGGL((k_rev_select_leaving<true>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
+                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap);
+    LP_TRY(check_launch("k_rev_select_leaving"));
+  } else {
+    hipLaunchKernelGGL((k_rev_select_leaving<false>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
+                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap);
+    LP_TRY(check_launch("k_rev_select_leaving"));
+    hipLaunchKernelGGL(k_rev_pivot_vectors, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
+                       h->st, sh, h->mu, h->xB, h->BinvT, h->scaled, h->touched);
+    LP_TRY(check_launch("k_rev_pivot_vectors"));
+    hipLaunchKernelGGL(k_rev_finish_pivot, one, sel, 0, h->stream, h->st, sh, h->mu, h->cB, h->obj, h->basis, h->is_basic, h->touched,
+                       h->idx_upd, h->trace, h->trace_cap);
+    LP_TRY(check_launch("k_rev_finish_pivot"));
+  }
   return rev_enqueue_update(h);
 }
 
 // One iteration of the main loop (reference lp_revised_simplex_tableau.cc:235-299).
 int rev_enqueue_iteration(lpamd_rev_engine* h, int64_t ncols_active) {
   const RevShape& sh = h->sh;
-  LP_TRY(rev_colsum(h, h->Binv, sh.ldb, sh.m, sh.m, h->cB, nullptr, h->pvec));
-  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost));
-  hipLaunchKernelGGL((k_rev_select_entering<false>), dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, sh, ncols_active, h->cost,
-                     h->is_basic, h->Trm, h->colbuf);
-  LP_TRY(check_launch("k_rev_select_entering"));
+  LP_TRY(rev_rowdot(h));
+  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, nullptr, nullptr, ncols_active, h->pvec, h->obj, h->cost));
+  LP_TRY(rev_enqueue_entering(h, false, ncols_active));
   return rev_enqueue_pivot_tail(h, -1);
 }
 
@@ -232,11 +304,15 @@ int rev_compute_optimum(lpamd_rev_engine* h) {
 
 int rev_init_basis(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
-  HIP_TRY(hipMemsetAsync(h->Binv, 0, sizeof(double) * (size_t)sh.m * sh.ldb, h->stream));
   HIP_TRY(hipMemsetAsync(h->BinvT, 0, sizeof(double) * (size_t)sh.m * sh.ldb, h->stream));
   hipLaunchKernelGGL(k_rev_init_basis, dim3((unsigned)((sh.m + 255) / 256)), dim3(256), 0, h->stream, sh, h->basis, h->rows, h->Trm,
-                     h->obj, h->Binv, h->BinvT, h->xB, h->cB);
-  return check_launch("k_rev_init_basis");
+                     h->obj, h->BinvT, h->xB, h->cB);
+  LP_TRY(check_launch("k_rev_init_basis"));
+  // an initial entry below the zero-drop threshold survives until the first update, which
+  // therefore has to visit every row once
+  LP_TRY(rev_pull(h));
+  h->h_st.full_update = 1;
+  return rev_push(h);
 }
 
 // Feasibility phase (reference lp_revised_simplex_tableau.cc:92-197).
@@ -288,10 +364,14 @@ int rev_phase1(lpamd_rev_engine* h, int64_t max_pivots, int32_t* result) {
   for (int64_t i = 0; i < m; i++) {
     if (basis[i] < N) continue;
     LP_TRY(rev_ensure_trace(h, h->h_st.iter + 1));
-    LP_TRY(rev_colsum(h, h->Trm, sh.ldw, m, W0, h->Binv + i * sh.ldb, nullptr, h->cost));
-    hipLaunchKernelGGL((k_rev_select_entering<true>), dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, sh, W0, h->cost, h->is_basic,
-                       h->Trm, h->colbuf);
-    LP_TRY(check_launch("k_rev_select_entering"));
+    // row i of B^-1 (column i of the transposed storage) times the tableau = row i of B^-1 A
+    hipLaunchKernelGGL(k_rev_gather_wide, dim3((unsigned)((m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
+                       h->BinvT, sh.ldb, m, i, h->colbuf);
+    LP_TRY(check_launch("k_rev_gather_wide"));
+    hipLaunchKernelGGL(k_rev_list_nonzero, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, h->colbuf, m, h->idx_col);
+    LP_TRY(check_launch("k_rev_list_nonzero"));
+    LP_TRY(rev_colsum(h, h->Trm, sh.ldw, m, h->idx_col, &h->st->n_col, W0, h->colbuf, nullptr, h->cost));
+    LP_TRY(rev_enqueue_entering(h, true, W0));
     LP_TRY(rev_enqueue_pivot_tail(h, i));
     LP_TRY(rev_pull(h));
     if (h->h_st.status != ST_RUNNING) { *result = LPAMD_ERROR; return LPAMD_OK; }   // :165, a live assert upstream
@@ -329,6 +409,10 @@ int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_str
   } else {
     h->own_stream = true;
   }
+  if (const char* env = getenv("LPAMD_REV_COLSUM_VEC")) h->force_vec = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_ROWDOT_ROWS")) h->force_rowdot_rows = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_UPDATE_UNROLL")) h->force_update_unroll = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_SPLIT")) h->force_split = atoi(env);
   *out = h;
   return LPAMD_OK;
 }
@@ -481,12 +565,20 @@ int lpamd_rev_read_state(lpamd_rev_engine* h, double* Binv, double* BinvT, doubl
   if (!h->started) return set_err(LPAMD_E_STATE, "rev_read_state: rev_solve has not run");
   const RevShape& sh = h->sh;
   const size_t row = sizeof(double) * sh.m;
-  if (Binv) HIP_TRY(hipMemcpy2DAsync(Binv, row, h->Binv, sizeof(double) * sh.ldb, row, sh.m, hipMemcpyDeviceToHost, h->stream));
-  if (BinvT) HIP_TRY(hipMemcpy2DAsync(BinvT, row, h->BinvT, sizeof(double) * sh.ldb, row, sh.m, hipMemcpyDeviceToHost, h->stream));
+  std::vector<double> tmp;
+  double* bt = BinvT;
+  if (Binv && !BinvT) {
+    tmp.resize((size_t)sh.m * sh.m);
+    bt = tmp.data();
+  }
+  if (bt) HIP_TRY(hipMemcpy2DAsync(bt, row, h->BinvT, sizeof(double) * sh.ldb, row, sh.m, hipMemcpyDeviceToHost, h->stream));
   if (xB) HIP_TRY(hipMemcpyAsync(xB, h->xB, row, hipMemcpyDeviceToHost, h->stream));
   if (cB) HIP_TRY(hipMemcpyAsync(cB, h->cB, row, hipMemcpyDeviceToHost, h->stream));
   if (basis) HIP_TRY(hipMemcpyAsync(basis, h->basis, sizeof(int64_t) * sh.m, hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (Binv)
+    for (int64_t i = 0; i < sh.m; i++)
+      for (int64_t k = 0; k < sh.m; k++) Binv[i * sh.m + k] = bt[k * sh.m + i];
   return LPAMD_OK;
 }
 

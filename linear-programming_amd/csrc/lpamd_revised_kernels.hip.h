@@ -3,19 +3,25 @@
 // The method keeps the constraint matrix untouched and carries a dense inverse of
 // the basis instead (reference lp_revised_simplex_tableau.cc).  Every contraction of
 // the reference runs over its index in ascending order with each product and sum
-// rounded on its own, so a sum is never split across lanes here: one lane owns one
-// (or two adjacent) output entries and walks the contracted index sequentially,
-// while the lanes of a wavefront cover adjacent outputs, which makes every load
-// a coalesced row segment.
+// rounded on its own, so a sum is never split across lanes here: one lane owns an
+// output entry and walks the contracted index sequentially.  Terms whose
+// coefficient is an exact zero are left out (acc + x * 0 == acc for finite x, and an
+// accumulator that starts at +0.0 never becomes -0.0), which is what makes sparse
+// columns, sparse basis costs and sparse leaving rows cheap.
 //
 // Data layout (one GPU):
 //   Trm    row-major fp64 copy of the tableau, m rows of ldw doubles: columns
 //          0..N-1 variables, N the right-hand side, N+1+k the k-th artificial
 //          column of the feasibility phase (allocated only when that phase runs).
-//   Binv   row-major m x ldb: row i = basis position i, column r = constraint row.
-//   BinvT  its transpose, kept in step by the same update kernel, so that both
-//          B^-1 * column and c_B^T * B^-1 read rows of a row-major matrix.
-//   obj, cost  ldw doubles; xB, cB, pvec, mu, colbuf, scaled  ldb doubles.
+//   BinvT  the basis inverse stored transposed, row-major m x ldb: row k =
+//          constraint row, column i = basis position, BinvT[k][i] = B^-1[i][k].
+//          B^-1 * column then streams rows of BinvT (one lane per basis position),
+//          the rank-1 update touches only the rows k whose leaving-row entry is
+//          non-zero, and c_B^T * B^-1 is a dot product along every row, done through
+//          LDS tiles so that the global loads stay coalesced.
+//   obj, cost  ldw doubles; xB, cB, pvec, mu, colbuf, scaled  ldb doubles;
+//   idx_col, idx_upd  ldb int32: compacted index lists (non-zero entries of the
+//   entering column; rows of BinvT the pending update has to touch).
 #pragma once
 #include "lpamd_kernels.hip.h"
 
@@ -23,66 +29,121 @@ namespace lpamd {
 
 struct RevState {      // device resident, one per revised engine
   int32_t status;      // ST_* as in the tableau engine
-  int32_t pad0;
+  int32_t full_update; // 1: the next update visits every row (entries set at start-up may still need the zero drop)
   int64_t iter;        // pivots applied so far
   int64_t max_iter;    // pricing reports ST_LIMIT once iter reaches this
   int64_t e;           // entering column of the pivot in flight
   int64_t leaving;     // leaving basis position
   double ratio;
+  int32_t n_col;       // entries of idx_col
+  int32_t n_upd;       // entries of idx_upd
 };
 
 struct RevShape {
   int64_t m, N;        // rows; variables (right-hand side at column N)
   int64_t W;           // allocated columns: N + 1, or N + 1 + m with the artificial block
-  int64_t ldw, ldb;    // row pitch of Trm / of Binv and BinvT (multiples of 64 doubles)
+  int64_t ldw, ldb;    // row pitch of Trm / of BinvT (multiples of 64 doubles)
 };
 
 constexpr int kRevThreads = 256;
 constexpr int kRevSelectThreads = 1024;
 
-// out[j] = sum_r coef[r] * M[r * ld + j]  (r ascending, no zero drop inside the sum);
-// with kCost the result is flushz(base[j] + sum), the reduced cost of column j
-// (reference lp_revised_simplex_tableau.cc:236-238, :155, :280).
-// One lane owns columns 2t and 2t+1 (kVec == 2) or column t (kVec == 1); ld is even
-// and covers the rounded-up column count, padding entries are finite.
-template <int kVec, int kUnroll, bool kCost>
-__global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
-    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
-    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out) {
-  if (st->status != ST_RUNNING) return;
-  const int64_t j = ((int64_t)blockIdx.x * kRevThreads + threadIdx.x) * kVec;
-  if (j >= ncols) return;
-  const double* __restrict__ p = M + j;
-  double a0 = 0.0, a1 = 0.0;
-  int64_t r = 0;
-  if constexpr (kVec == 2) {
-    for (; r + kUnroll <= nrows; r += kUnroll) {
+// Exclusive prefix sum of one int per thread over a kRevSelectThreads block.
+__device__ __forceinline__ int block_exclusive_scan(int v, int* s_w /* [kRevSelectThreads / kWave + 1] */, int& total) {
+  constexpr int kWaves = kRevSelectThreads / kWave;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int o = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += o;
+  }
+  if (lane == kWave - 1) s_w[wave] = inc;
+  __syncthreads();
+  if (wave == 0) {
+    const int w = lane < kWaves ? s_w[lane] : 0;
+    int winc = w;
+#pragma unroll
+    for (int off = 1; off < kWaves; off <<= 1) {
+      const int o = __shfl_up(winc, off, kWave);
+      if (lane >= off) winc += o;
+    }
+    if (lane < kWaves) s_w[lane] = winc - w;
+    if (lane == kWaves - 1) s_w[kWaves] = winc;
+  }
+  __syncthreads();
+  total = s_w[kWaves];
+  const int res = s_w[wave] + inc - v;
+  __syncthreads();   // s_w may be reused by the caller
+  return res;
+}
+
+// Sequential sum of coef[r] * (p[r * ld], p[r * ld + 1]) over rows 0..n-1 (kIndexed: rows idx[0..n)),
+// kUnroll row loads in flight per lane.
+template <int kVec, int kUnroll, bool kIndexed>
+__device__ __forceinline__ void colsum_rows(const double* __restrict__ p, int64_t ld, int64_t n, const int32_t* __restrict__ idx,
+                                            const double* __restrict__ coef, double& a0, double& a1) {
+  int64_t t = 0;
+  for (; t + kUnroll <= n; t += kUnroll) {
+    int64_t r[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) {
+      if constexpr (kIndexed) r[u] = idx[t + u]; else r[u] = t + u;
+    }
+    if constexpr (kVec == 2) {
       double2 v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) v[u] = *reinterpret_cast<const double2*>(p + (r + u) * ld);
+      for (int u = 0; u < kUnroll; u++) v[u] = *reinterpret_cast<const double2*>(p + r[u] * ld);
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
-        const double c = coef[r + u];
+        const double c = coef[r[u]];
         a0 = __dadd_rn(a0, __dmul_rn(c, v[u].x));
         a1 = __dadd_rn(a1, __dmul_rn(c, v[u].y));
       }
-    }
-    for (; r < nrows; r++) {
-      const double2 v = *reinterpret_cast<const double2*>(p + r * ld);
-      const double c = coef[r];
-      a0 = __dadd_rn(a0, __dmul_rn(c, v.x));
-      a1 = __dadd_rn(a1, __dmul_rn(c, v.y));
-    }
-  } else {
-    for (; r + kUnroll <= nrows; r += kUnroll) {
+    } else {
       double v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) v[u] = p[(r + u) * ld];
+      for (int u = 0; u < kUnroll; u++) v[u] = p[r[u] * ld];
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) a0 = __dadd_rn(a0, __dmul_rn(coef[r + u], v[u]));
+      for (int u = 0; u < kUnroll; u++) a0 = __dadd_rn(a0, __dmul_rn(coef[r[u]], v[u]));
     }
-    for (; r < nrows; r++) a0 = __dadd_rn(a0, __dmul_rn(coef[r], p[r * ld]));
   }
+  for (; t < n; t++) {
+    int64_t r = t;
+    if constexpr (kIndexed) r = idx[t];
+    const double c = coef[r];
+    if constexpr (kVec == 2) {
+      const double2 v = *reinterpret_cast<const double2*>(p + r * ld);
+      a0 = __dadd_rn(a0, __dmul_rn(c, v.x));
+      a1 = __dadd_rn(a1, __dmul_rn(c, v.y));
+    } else {
+      a0 = __dadd_rn(a0, __dmul_rn(c, p[r * ld]));
+    }
+  }
+}
+
+// out[j] = sum over rows r (ascending) of coef[r] * M[r * ld + j]; with kCost the
+// result is flushz(base[j] + sum), the reduced cost of column j (reference
+// lp_revised_simplex_tableau.cc:237-238; Tableau::Times, :155 and :280).
+// kIndexed: idx[0..*count) lists the rows with a non-zero coefficient; the list is
+// used when it drops at least half of the rows (following it costs a dependent
+// scalar load per row), otherwise all rows are streamed.
+// One lane owns columns 2t and 2t+1 (kVec == 2) or column t (kVec == 1); ld is even
+// and covers the rounded-up column count, padding entries are finite.
+template <int kVec, int kUnroll, bool kCost, bool kIndexed>
+__global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, const int32_t* __restrict__ idx,
+    const int32_t* __restrict__ count, int64_t ncols, const double* __restrict__ coef, const double* __restrict__ base,
+    double* __restrict__ out) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kVec;   // 64..256 lanes per workgroup
+  if (j >= ncols) return;
+  const double* __restrict__ p = M + j;
+  double a0 = 0.0, a1 = 0.0;
+  bool listed = false;
+  if constexpr (kIndexed) listed = 2 * (int64_t)*count <= nrows;
+  if (kIndexed && listed) colsum_rows<kVec, kUnroll, true>(p, ld, *count, idx, coef, a0, a1);
+  else colsum_rows<kVec, kUnroll, false>(p, ld, nrows, idx, coef, a0, a1);
   if constexpr (kCost) {
     a0 = flushz(__dadd_rn(base[j], a0));
     if (kVec == 2 && j + 1 < ncols) a1 = flushz(__dadd_rn(base[j + 1], a1));
@@ -91,32 +152,143 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
   if (kVec == 2 && j + 1 < ncols) out[j + 1] = a1;
 }
 
+// out[r] = sum_i coef[i] * M[r * ld + i], i ascending: a dot product along every row
+// (p = c_B^T * B^-1 on the transposed inverse, reference :236).  A workgroup owns kR
+// rows and sweeps the columns in chunks of kC = 4096 / kR: all 256 lanes load the
+// kR x kC tile with coalesced 16-byte accesses into registers, park it in LDS
+// (odd pitch, conflict-free for the transposed read), and kR lanes of the first
+// wavefront add their row of the tile in order while the loads of the next chunk
+// are already in flight.  Chunks whose coefficients are all zero are skipped.
+template <int kR>
+__global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
+    const double* __restrict__ coef, double* __restrict__ out) {
+  constexpr int kC = 4096 / kR;
+  constexpr int kPitch = kC + 1;
+  constexpr int kRowsPerPass = 2 * kRevThreads / kC;
+  constexpr int kPasses = kR / kRowsPerPass;
+  __shared__ double tile[kR * kPitch];
+  __shared__ double s_coef[kC];
+  if (st->status != ST_RUNNING) return;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int64_t r0 = (int64_t)blockIdx.x * kR;
+  const int lrow = tid / (kC / 2), lcol = (tid % (kC / 2)) * 2;
+  const int64_t nchunks = (ncols + kC - 1) / kC;
+  auto next_active = [&](int64_t c) {   // same answer in every wavefront: they test the same data
+    for (; c < nchunks; c++) {
+      bool nz = false;
+      for (int q = lane; q < kC; q += kWave) {
+        const int64_t i = c * kC + q;
+        nz |= i < ncols && coef[i] != 0.0;
+      }
+      if (__ballot(nz) != 0) break;
+    }
+    return c;
+  };
+  double2 reg[kPasses];
+  double creg = 0.0;
+  auto issue_loads = [&](int64_t c) {
+    const int64_t col = c * kC + lcol;
+#pragma unroll
+    for (int q = 0; q < kPasses; q++) {
+      const int64_t gr = r0 + q * kRowsPerPass + lrow;
+      reg[q] = (gr < nrows && col < ld) ? *reinterpret_cast<const double2*>(M + gr * ld + col) : make_double2(0.0, 0.0);
+    }
+    if (tid < kC) creg = c * kC + tid < ncols ? coef[c * kC + tid] : 0.0;
+  };
+  double acc = 0.0;
+  int64_t c = next_active(0);
+  if (c < nchunks) issue_loads(c);
+  while (c < nchunks) {
+    __syncthreads();   // the previous tile has been consumed
+#pragma unroll
+    for (int q = 0; q < kPasses; q++) {
+      double* dst = tile + (q * kRowsPerPass + lrow) * kPitch + lcol;
+      dst[0] = reg[q].x;
+      dst[1] = reg[q].y;
+    }
+    if (tid < kC) s_coef[tid] = creg;
+    __syncthreads();
+    const int64_t cn = next_active(c + 1);
+    if (cn < nchunks) issue_loads(cn);
+    if (tid < kR) {
+      const double* row = tile + tid * kPitch;
+#pragma unroll 16
+      for (int b = 0; b < kC; b++) acc = __dadd_rn(acc, __dmul_rn(s_coef[b], row[b]));
+    }
+    c = cn;
+  }
+  if (tid < kR && r0 + tid < nrows) out[r0 + tid] = acc;
+}
+
+// colbuf[r] = M[r * ld + col] for this thread's run of rows [r_begin, r_end) and, over the whole
+// workgroup, the ascending list of the rows with a non-zero entry.  The strided loads go out
+// eight at a time: a single workgroup hides their latency only through loads in flight.
+__device__ __forceinline__ void gather_column_and_list(const double* __restrict__ M, int64_t ld, int64_t col, int64_t r_begin,
+                                                       int64_t r_end, double* __restrict__ colbuf, int32_t* __restrict__ idx,
+                                                       int* s_w, int32_t* __restrict__ count) {
+  int nz = 0;
+  for (int64_t rb = r_begin; rb < r_end; rb += 8) {
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = rb + q < r_end ? M[(rb + q) * ld + col] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      if (rb + q < r_end) {
+        colbuf[rb + q] = v[q];
+        nz += v[q] != 0.0;
+      }
+  }
+  int total;
+  int at = block_exclusive_scan(nz, s_w, total);
+  for (int64_t r = r_begin; r < r_end; r++)
+    if (colbuf[r] != 0.0) idx[at++] = (int32_t)r;
+  if (threadIdx.x == 0) *count = total;
+}
+
 // kFirstNonZero == false: entering column = non-basic column (not the right-hand
 //   side) with the most negative reduced cost, lowest index on ties; none left means
 //   the basis is optimal (reference lp_revised_simplex_tableau.cc:240-252).
 // kFirstNonZero == true: lowest non-basic column whose probe entry is non-zero, the
 //   column that replaces an artificial variable still basic after the feasibility
 //   phase (reference :148-163); none is ST_ERROR (the reference asserts).
-// The winner's column of Trm is then copied to colbuf for the B^-1 * column product.
-template <bool kFirstNonZero>
+// With kGather the winner's column of Trm is then copied to colbuf, and the rows of its
+// non-zero entries are listed in ascending order in idx_col for the B^-1 * column
+// product; large problems leave that to k_rev_gather_wide + k_rev_list_nonzero, whose
+// strided loads (one page per row) are spread over the whole chip.
+template <bool kFirstNonZero, bool kGather>
 __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering(
     RevState* __restrict__ st, RevShape sh, int64_t ncols_active, const double* __restrict__ cost,
-    const uint8_t* __restrict__ is_basic, const double* __restrict__ Trm, double* __restrict__ colbuf) {
+    const uint8_t* __restrict__ is_basic, const double* __restrict__ Trm, double* __restrict__ colbuf,
+    int32_t* __restrict__ idx_col) {
   __shared__ double s_v[kRevSelectThreads / kWave];
   __shared__ int64_t s_i[kRevSelectThreads / kWave];
+  __shared__ int s_w[kRevSelectThreads / kWave + 1];
   __shared__ int64_t s_e;
   if (st->status != ST_RUNNING) return;
   const bool limit = !kFirstNonZero && st->iter >= st->max_iter;
   double bv = 0.0;
   int64_t bi = -1;
-  for (int64_t j = threadIdx.x; j < ncols_active; j += kRevSelectThreads) {
-    if (j == sh.N || is_basic[j]) continue;
-    const double c = cost[j];
-    if (kFirstNonZero) {
-      if (!is_zero(c)) take_min(bv, bi, (double)j, j);
-    } else {
-      if ((float)c > -1e-6f) continue;   // _IsNonNegative, reference base.h:65
-      take_min(bv, bi, c, j);
+  // a single workgroup hides the load latency only through loads in flight: eight per lane
+  for (int64_t jb = threadIdx.x; jb < ncols_active; jb += 8 * kRevSelectThreads) {
+    double c[8];
+    uint8_t basic[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int64_t j = jb + q * kRevSelectThreads;
+      c[q] = j < ncols_active ? cost[j] : 0.0;
+      basic[q] = j < ncols_active ? is_basic[j] : 1;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int64_t j = jb + q * kRevSelectThreads;
+      if (j >= ncols_active || j == sh.N || basic[q]) continue;
+      if (kFirstNonZero) {
+        if (!is_zero(c[q])) take_min(bv, bi, (double)j, j);
+      } else {
+        if ((float)c[q] > -1e-6f) continue;   // _IsNonNegative, reference base.h:65
+        take_min(bv, bi, c[q], j);
+      }
     }
   }
   block_arg<false, kRevSelectThreads>(bv, bi, s_v, s_i);
@@ -128,34 +300,93 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering(
   }
   __syncthreads();
   const int64_t e = s_e;
-  if (e < 0) return;
-  for (int64_t r = threadIdx.x; r < sh.m; r += kRevSelectThreads) colbuf[r] = Trm[r * sh.ldw + e];
+  if (!kGather || e < 0) return;
+  // every thread gathers a contiguous run of rows, which keeps the list ordered
+  const int64_t seg = (sh.m + kRevSelectThreads - 1) / kRevSelectThreads;
+  const int64_t r_begin = threadIdx.x * seg, r_end = r_begin + seg < sh.m ? r_begin + seg : sh.m;
+  gather_column_and_list(Trm, sh.ldw, e, r_begin, r_end, colbuf, idx_col, s_w, &st->n_col);
+}
+
+// out[r] = M[r * ld + col] with one row per lane over the whole grid; col < 0 reads the
+// entering column chosen by k_rev_select_entering.
+__global__ __launch_bounds__(kRevThreads) void k_rev_gather_wide(
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t col, double* __restrict__ out) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t r = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
+  if (col < 0) col = st->e;
+  if (r < nrows) out[r] = M[r * ld + col];
+}
+
+// Ascending list of the indices i < n with flag(i) set, where flag(i) is v[i] != 0 (v given) or
+// bytes[i] != 0; one workgroup, every thread a contiguous run, loads eight at a time.
+__device__ __forceinline__ void list_flagged(const double* __restrict__ v, const uint8_t* __restrict__ bytes, int64_t n,
+                                             int32_t* __restrict__ idx, int* s_w, int32_t* __restrict__ count) {
+  const int64_t seg = (n + kRevSelectThreads - 1) / kRevSelectThreads;
+  const int64_t begin = threadIdx.x * seg, end = begin + seg < n ? begin + seg : n;
+  int hits = 0;
+  for (int64_t b = begin; b < end; b += 8) {
+    bool f[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) f[q] = b + q < end && (v ? v[b + q] != 0.0 : bytes[b + q] != 0);
+#pragma unroll
+    for (int q = 0; q < 8; q++) hits += f[q];
+  }
+  int total;
+  int at = block_exclusive_scan(hits, s_w, total);
+  for (int64_t i = begin; i < end; i++)
+    if (v ? v[i] != 0.0 : bytes[i] != 0) idx[at++] = (int32_t)i;
+  if (threadIdx.x == 0) *count = total;
+}
+
+__global__ __launch_bounds__(kRevSelectThreads) void k_rev_list_nonzero(
+    RevState* __restrict__ st, const double* __restrict__ v, int64_t n, int32_t* __restrict__ idx) {
+  __shared__ int s_w[kRevSelectThreads / kWave + 1];
+  if (st->status != ST_RUNNING) return;
+  list_flagged(v, nullptr, n, idx, s_w, &st->n_col);
 }
 
 // Ratio test over mu = B^-1 * column (reference :282-297) and everything of the
 // pivot that is a vector operation (reference :42-60): the basic solution moves
-// along mu without a zero drop, the leaving row of the inverse is scaled by
-// -1 / mu[leaving] into `scaled`, mu[leaving] becomes zero, the basis bookkeeping
-// and the trace are written.  forced_leaving >= 0 skips the test (replacement of a
-// basic artificial variable, reference :156-160).
+// along mu without a zero drop, the leaving row of the inverse (column `leaving`
+// of BinvT) is scaled by -1 / mu[leaving] into `scaled`, mu[leaving] becomes zero,
+// the basis bookkeeping and the trace are written, and the rows of BinvT the rank-1
+// update has to visit are listed in idx_upd: those whose leaving-row entry is
+// non-zero before or after the scaling (all rows while full_update is set).
+// forced_leaving >= 0 skips the test (replacement of a basic artificial variable,
+// reference :156-160).
+// Without kVectors the kernel stops after the test (leaving position and ratio in the
+// state); k_rev_pivot_vectors and k_rev_finish_pivot then do the rest over the whole chip.
+template <bool kVectors>
 __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
     RevState* __restrict__ st, RevShape sh, int64_t forced_leaving, double* __restrict__ mu, double* __restrict__ xB,
     double* __restrict__ cB, const double* __restrict__ obj, int64_t* __restrict__ basis, uint8_t* __restrict__ is_basic,
-    const double* __restrict__ Binv, double* __restrict__ scaled, int64_t* __restrict__ trace, int64_t trace_cap) {
+    const double* __restrict__ BinvT, double* __restrict__ scaled, int32_t* __restrict__ idx_upd, int64_t* __restrict__ trace,
+    int64_t trace_cap) {
   __shared__ double s_v[kRevSelectThreads / kWave];
   __shared__ int64_t s_i[kRevSelectThreads / kWave];
+  __shared__ int s_w[kRevSelectThreads / kWave + 1];
   __shared__ double s_q;
   __shared__ int64_t s_l;
   if (st->status != ST_RUNNING) return;
   const int64_t e = st->e, it = st->iter;
+  const bool full = st->full_update != 0;
   double bv = 0.0;
   int64_t bi = -1;
   if (forced_leaving < 0) {
-    for (int64_t i = threadIdx.x; i < sh.m; i += kRevSelectThreads) {
-      const double mi = mu[i];
-      if (!is_neg(mi)) continue;
-      const double q = -(xB[i] / mi);
-      if (q < DBL_MAX) take_min(bv, bi, q, i);
+    for (int64_t ib = threadIdx.x; ib < sh.m; ib += 8 * kRevSelectThreads) {
+      double mi[8], xi[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        const int64_t i = ib + q * kRevSelectThreads;
+        mi[q] = i < sh.m ? mu[i] : 0.0;
+        xi[q] = i < sh.m ? xB[i] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        if (!is_neg(mi[q])) continue;
+        const double ratio_q = -(xi[q] / mi[q]);
+        if (ratio_q < DBL_MAX) take_min(bv, bi, ratio_q, ib + q * kRevSelectThreads);
+      }
     }
     block_arg<false, kRevSelectThreads>(bv, bi, s_v, s_i);
   } else {
@@ -166,18 +397,47 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
     s_l = bi;
     s_q = bv;
     if (bi < 0) st->status = ST_UNBOUNDED;
+    else if (!kVectors) { st->leaving = bi; st->ratio = bv; }
   }
+  if (!kVectors) return;
   __syncthreads();
   const int64_t l = s_l;
   if (l < 0) return;
   const double ratio = s_q;
   const double s = -1.0 / mu[l];
-  const double* __restrict__ rowl = Binv + l * sh.ldb;
-  for (int64_t i = threadIdx.x; i < sh.m; i += kRevSelectThreads) {
-    xB[i] = i == l ? ratio : __dadd_rn(xB[i], __dmul_rn(mu[i], ratio));
-    scaled[i] = __dmul_rn(rowl[i], s);
+  const int64_t seg = (sh.m + kRevSelectThreads - 1) / kRevSelectThreads;
+  const int64_t k_begin = threadIdx.x * seg, k_end = k_begin + seg < sh.m ? k_begin + seg : sh.m;
+  int touched = 0;
+  uint64_t mask = 0;   // bit (k - k_begin) for the first 64 rows of the run; longer runs re-read
+  for (int64_t kb = k_begin; kb < k_end; kb += 8) {
+    double old[8], xk[8], mk[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {   // strided: eight in flight
+      const bool in = kb + q < k_end;
+      old[q] = in ? BinvT[(kb + q) * sh.ldb + l] : 0.0;
+      xk[q] = in ? xB[kb + q] : 0.0;
+      mk[q] = in ? mu[kb + q] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int64_t k = kb + q;
+      if (k < k_end) {
+        xB[k] = k == l ? ratio : __dadd_rn(xk[q], __dmul_rn(mk[q], ratio));
+        const double sc = __dmul_rn(old[q], s);
+        scaled[k] = sc;
+        const bool hit = full || old[q] != 0.0 || sc != 0.0;
+        touched += hit;
+        if (hit && k - k_begin < 64) mask |= 1ull << (k - k_begin);
+      }
+    }
   }
-  __syncthreads();   // every lane has read mu[l]
+  int total;
+  int at = block_exclusive_scan(touched, s_w, total);   // also orders the reads of mu[l] above before the write below
+  for (int64_t k = k_begin; k < k_end; k++) {
+    const bool hit = k - k_begin < 64 ? ((mask >> (k - k_begin)) & 1) != 0
+                                      : (full || BinvT[k * sh.ldb + l] != 0.0 || scaled[k] != 0.0);
+    if (hit) idx_upd[at++] = (int32_t)k;
+  }
   if (threadIdx.x == 0) {
     mu[l] = 0.0;
     is_basic[e] = 1;
@@ -188,61 +448,105 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
     st->leaving = l;
     st->ratio = ratio;
     st->iter = it + 1;
+    st->n_upd = total;
+    st->full_update = 0;
   }
 }
 
-// Binv = flushz(Binv' + mu (x) scaled) over every entry, where Binv' is Binv with
-// its leaving row replaced by `scaled` (reference :56-61: the zero drop of
-// Tableau::Add reaches all entries, the scaled row included).  blockIdx.z == 1
-// applies the same update to the transposed copy: there the roles of the two
-// vectors swap and the replaced line is column `leaving`.
-// Lane t of block x owns columns 2 * (256 x + t) .. +1 of a chunk of rows.
-template <int kUnroll>
-__global__ __launch_bounds__(kRevThreads) void k_rev_update(
-    const RevState* __restrict__ st, RevShape sh, double* __restrict__ Binv, double* __restrict__ BinvT,
-    const double* __restrict__ mu, const double* __restrict__ scaled, int64_t rows_per_block) {
+// Vector part of the pivot for the position and ratio left by k_rev_select_leaving<false>,
+// one row per lane over the whole grid: basic solution, scaled leaving row, and a byte per
+// row of BinvT telling whether the update has to visit it.
+__global__ __launch_bounds__(kRevThreads) void k_rev_pivot_vectors(
+    const RevState* __restrict__ st, RevShape sh, const double* __restrict__ mu, double* __restrict__ xB,
+    const double* __restrict__ BinvT, double* __restrict__ scaled, uint8_t* __restrict__ touched) {
   if (st->status != ST_RUNNING) return;
-  const bool tr = blockIdx.z == 1;
+  const int64_t k = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
+  if (k >= sh.m) return;
   const int64_t l = st->leaving;
-  double* __restrict__ M = tr ? BinvT : Binv;
-  const double* __restrict__ u = tr ? scaled : mu;   // indexed by matrix row
-  const double* __restrict__ v = tr ? mu : scaled;   // indexed by matrix column
-  const int64_t b = ((int64_t)blockIdx.x * kRevThreads + threadIdx.x) * 2;
-  if (b >= sh.m) return;
-  const double v0 = v[b], v1 = b + 1 < sh.m ? v[b + 1] : 0.0;
-  const int64_t a_begin = (int64_t)blockIdx.y * rows_per_block;
-  const int64_t a_end = a_begin + rows_per_block < sh.m ? a_begin + rows_per_block : sh.m;
-  double* __restrict__ p = M + b;
-  auto apply = [&](double2 x, int64_t a) {
-    const double ua = u[a];
-    if (!tr && a == l) { x.x = v0; x.y = v1; }
-    if (tr) {
-      if (b == l) x.x = ua;
-      if (b + 1 == l) x.y = ua;
-    }
-    x.x = flushz(__dadd_rn(x.x, __dmul_rn(ua, v0)));
-    x.y = flushz(__dadd_rn(x.y, __dmul_rn(ua, v1)));
-    return x;
-  };
-  int64_t a = a_begin;
-  for (; a + kUnroll <= a_end; a += kUnroll) {
-    double2 x[kUnroll];
+  const double ratio = st->ratio;
+  const double s = -1.0 / mu[l];
+  const double old = BinvT[k * sh.ldb + l];
+  xB[k] = k == l ? ratio : __dadd_rn(xB[k], __dmul_rn(mu[k], ratio));
+  const double sc = __dmul_rn(old, s);
+  scaled[k] = sc;
+  touched[k] = (st->full_update != 0 || old != 0.0 || sc != 0.0) ? 1 : 0;
+}
+
+// Closes the pivot after k_rev_pivot_vectors: list of the rows to update, mu[leaving] = 0,
+// basis bookkeeping, trace, pivot count.
+__global__ __launch_bounds__(kRevSelectThreads) void k_rev_finish_pivot(
+    RevState* __restrict__ st, RevShape sh, double* __restrict__ mu, double* __restrict__ cB, const double* __restrict__ obj,
+    int64_t* __restrict__ basis, uint8_t* __restrict__ is_basic, const uint8_t* __restrict__ touched, int32_t* __restrict__ idx_upd,
+    int64_t* __restrict__ trace, int64_t trace_cap) {
+  __shared__ int s_w[kRevSelectThreads / kWave + 1];
+  if (st->status != ST_RUNNING) return;
+  const int64_t e = st->e, it = st->iter, l = st->leaving;
+  list_flagged(nullptr, touched, sh.m, idx_upd, s_w, &st->n_upd);
+  if (threadIdx.x == 0) {
+    mu[l] = 0.0;
+    is_basic[e] = 1;
+    is_basic[basis[l]] = 0;
+    basis[l] = e;
+    cB[l] = obj[e];
+    if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = l; }
+    st->iter = it + 1;
+    st->full_update = 0;
+  }
+}
+
+// B^-1 = flushz(B^-1' + mu (x) scaled), where B^-1' is B^-1 with its leaving row
+// replaced by `scaled` (reference :56-61: the zero drop of Tableau::Add reaches every
+// entry, the scaled row included).  On the transposed storage that is, for every
+// listed row k: BinvT[k][i] = flushz(x + scaled[k] * mu[i]) with x = scaled[k] for
+// i == leaving and the stored value otherwise.  Rows that are not listed have
+// scaled[k] == 0 and a zero leaving-row entry, so none of their entries would change
+// (every stored entry is already a fixed point of the zero drop after the first,
+// full, update).  A work item is one run of kUnroll * 256 16-byte vectors of one
+// row; all loads of a run are issued before its first store.
+template <int kUnroll>
+__global__ __launch_bounds__(kRevThreads, 2) void k_rev_update(
+    const RevState* __restrict__ st, RevShape sh, double* __restrict__ BinvT, const double* __restrict__ mu,
+    const double* __restrict__ scaled, const int32_t* __restrict__ idx_upd) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t l = st->leaving;
+  const int n_vec = (int)(sh.ldb / 2);
+  constexpr int kRun = kUnroll * kRevThreads;
+  const int n_runs = (n_vec + kRun - 1) / kRun;
+  const int64_t n_items = (int64_t)st->n_upd * n_runs;
+  const double2* __restrict__ mu2 = reinterpret_cast<const double2*>(mu);
+  for (int64_t w = blockIdx.x; w < n_items; w += gridDim.x) {
+    const int64_t k = idx_upd[w / n_runs];
+    const int v0 = (int)(w % n_runs) * kRun + threadIdx.x;
+    const double u = scaled[k];
+    double2* __restrict__ p = reinterpret_cast<double2*>(BinvT + k * sh.ldb);
+    double2 x[kUnroll], c[kUnroll];
 #pragma unroll
-    for (int k = 0; k < kUnroll; k++) x[k] = *reinterpret_cast<const double2*>(p + (a + k) * sh.ldb);
+    for (int q = 0; q < kUnroll; q++) {
+      const int v = v0 + q * kRevThreads;
+      if (v < n_vec) { x[q] = p[v]; c[q] = mu2[v]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < kUnroll; k++) *reinterpret_cast<double2*>(p + (a + k) * sh.ldb) = apply(x[k], a + k);
+    for (int q = 0; q < kUnroll; q++) {
+      const int v = v0 + q * kRevThreads;
+      if (v < n_vec) {
+        if (2 * (int64_t)v == l) x[q].x = u;
+        if (2 * (int64_t)v + 1 == l) x[q].y = u;
+        x[q].x = flushz(__dadd_rn(x[q].x, __dmul_rn(c[q].x, u)));
+        x[q].y = flushz(__dadd_rn(x[q].y, __dmul_rn(c[q].y, u)));
+        p[v] = x[q];
+      }
+    }
   }
-  for (; a < a_end; a++) *reinterpret_cast<double2*>(p + a * sh.ldb) = apply(*reinterpret_cast<const double2*>(p + a * sh.ldb), a);
 }
 
 // ---- set-up -----------------------------------------------------------------
 // Basis of slack or artificial columns: each has one non-zero entry v at row
 // rows[i], so the inverse holds 1 / -v at (i, rows[i]) and the basic solution is
-// b / -v (reference :212-233).  Binv and BinvT are zero on entry.
+// b / -v (reference :212-233).  BinvT is zero on entry.
 __global__ void k_rev_init_basis(RevShape sh, const int64_t* __restrict__ basis, const int64_t* __restrict__ rows,
-                                 const double* __restrict__ Trm, const double* __restrict__ obj, double* __restrict__ Binv,
-                                 double* __restrict__ BinvT, double* __restrict__ xB, double* __restrict__ cB) {
+                                 const double* __restrict__ Trm, const double* __restrict__ obj, double* __restrict__ BinvT,
+                                 double* __restrict__ xB, double* __restrict__ cB) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sh.m) return;
   const int64_t bcol = basis[i], r = rows[i];
@@ -252,7 +556,6 @@ __global__ void k_rev_init_basis(RevShape sh, const int64_t* __restrict__ basis,
     const double v = Trm[r * sh.ldw + bcol];
     x = Trm[r * sh.ldw + sh.N] / (-v);
     const double inv = 1.0 / (-v);
-    Binv[i * sh.ldb + r] = inv;
     BinvT[r * sh.ldb + i] = inv;
   }
   xB[i] = x;

@@ -338,11 +338,12 @@ class RevisedTableauEngine:
         _ck(self.L.lpamd_rev_trace(self.h, e.ctypes.data, l.ctypes.data, n, ctypes.byref(got)))
         return list(zip(e[:got.value].tolist(), l[:got.value].tolist()))
 
-    def read_state(self, matrices=True):
+    def read_state(self, inverse=True, transposed=True):
+        """(Binv, BinvT, xB, cB, basis); a matrix that is not asked for comes back as None."""
         m = self.m
-        Binv = np.zeros((m, m), dtype=np.float64) if matrices else None
-        BinvT = np.zeros((m, m), dtype=np.float64) if matrices else None
+        Binv = np.zeros((m, m), dtype=np.float64) if inverse else None
+        BinvT = np.zeros((m, m), dtype=np.float64) if transposed else None
         xB, cB, basis = np.zeros(m), np.zeros(m), np.zeros(m, dtype=np.int64)
-        _ck(self.L.lpamd_rev_read_state(self.h, Binv.ctypes.data if matrices else None, BinvT.ctypes.data if matrices else None,
+        _ck(self.L.lpamd_rev_read_state(self.h, Binv.ctypes.data if inverse else None, BinvT.ctypes.data if transposed else None,
                                         xB.ctypes.data, cB.ctypes.data, basis.ctypes.data))
         return Binv, BinvT, xB, cB, basis

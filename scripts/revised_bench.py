@@ -33,12 +33,13 @@ def main():
     dt = time.perf_counter() - t0
     k = done - a.warmup
     m, W = a.m, a.n + a.m + 1
-    # algorithmic HBM bytes of one iteration: c_B^T B^-1 and B^-1 column read the inverse once each,
-    # pricing reads the tableau once, the rank-1 update reads and writes the inverse and its transpose
-    bytes_iter = 8.0 * (m * m * 2 + m * W + 4 * m * m)
+    # HBM bytes every iteration streams on a dense LP: the pricing product reads the tableau once and
+    # B^-1 * column reads the inverse once; c_B^T * B^-1 and the rank-1 update only touch the parts
+    # with non-zero multipliers (up to 8 m^2 and 16 m^2 more when the inverse has filled in)
+    dense_bytes = 8.0 * (m * W + m * m)
     print(json.dumps({"metric": "revised_simplex_pivots_per_second", "value": k / dt, "ms_per_pivot": 1e3 * dt / max(k, 1),
-                      "pivots": k, "result": res, "m": a.m, "n": a.n, "algorithmic_GB_per_pivot": bytes_iter / 1e9,
-                      "achieved_GBps": bytes_iter * k / dt / 1e9}))
+                      "pivots": k, "result": res, "m": a.m, "n": a.n, "dense_products_GB_per_pivot": dense_bytes / 1e9,
+                      "dense_products_GBps": dense_bytes * k / dt / 1e9}))
     eng.close()
 
 

@@ -80,3 +80,5 @@ def test_device_entry_points_fail_loudly_without_gpu():
     lp = lpamd_pkg()
     with pytest.raises(lp.LpamdError, match="no HIP device"):
         lp.TableauEngine(4, 8)
+    with pytest.raises(lp.LpamdError, match="no HIP device"):
+        lp.RevisedTableauEngine(4, 8)

@@ -71,6 +71,60 @@ def test_revised_synthetic_trace_and_inverse(lpamd, m, n, seed):
     eng.close()
 
 
+@pytest.mark.parametrize("knobs", [{"LPAMD_REV_ROWDOT_ROWS": "64"}, {"LPAMD_REV_UPDATE_UNROLL": "16"},
+                                   {"LPAMD_REV_COLSUM_VEC": "2"}, {"LPAMD_REV_SPLIT": "1"},
+                                   {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_COLSUM_VEC": "2",
+                                    "LPAMD_REV_SPLIT": "1"}])
+@pytest.mark.parametrize("m,n,seed", [(200, 333, 4), (65, 129, 5)])
+def test_revised_large_problem_kernel_shapes_on_small_lps(lpamd, monkeypatch, knobs, m, n, seed):
+    """The kernel variants picked for large m / wide tableaus, forced on small LPs the oracle solves fully."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    rt = lo.RevisedTableau(dt.T, dt.obj, dt.is_basic, n + m, False)
+    want = rt.solve()
+    eng = lpamd.RevisedTableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    res, npiv = eng.solve()
+    assert res == want and npiv == rt.n_pivots
+    assert eng.trace() == rt.trace()
+    assert_same_state(eng, rt)
+    eng.close()
+
+
+def test_revised_phase1_with_large_problem_kernel_shapes(lpamd, monkeypatch):
+    for k, v in {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_COLSUM_VEC": "2",
+                 "LPAMD_REV_SPLIT": "1"}.items():
+        monkeypatch.setenv(k, v)
+    tab, rt = lo.revised_from_text(case_text("israel"))
+    want = rt.solve()
+    eng = upload(lpamd, tab)
+    res, n = eng.solve()
+    assert res == want == lpamd.SOLVED and eng.trace() == rt.trace()
+    assert_same_state(eng, rt)
+    eng.close()
+
+
+def test_revised_wide_tableau_and_many_rows(lpamd):
+    """Default kernel selection at sizes that switch variants: W >= 65536 (two columns per lane in
+    the pricing product) and m >= 16384 (64-row tiles, 16-deep update runs); first pivots only."""
+    for m, n, seed, piv in [(64, 70000, 11, 12), (16384, 300, 12, 4)]:
+        dt = lo.DenseTableau.synthetic(m, n, seed)
+        rt = lo.RevisedTableau(dt.T, dt.obj, dt.is_basic, n + m, False)
+        del dt
+        want = rt.solve(max_pivots=piv)
+        eng = lpamd.RevisedTableauEngine(m, n + m)
+        eng.fill_synthetic(n, seed)
+        res, npiv = eng.solve(max_pivots=piv)
+        assert res == want and npiv == rt.n_pivots
+        assert eng.trace() == rt.trace()
+        _, BinvT, xB, cB, basis = eng.read_state(inverse=False)
+        assert np.array_equal(basis, rt.basis) and np.array_equal(bits(xB), bits(rt.xB)) and np.array_equal(bits(cB), bits(rt.cB))
+        assert np.array_equal(BinvT.view(np.uint64), rt.Binv.T.view(np.uint64)), "basis inverse differs"
+        eng.close()
+        del rt, BinvT
+
+
 def test_revised_pivot_limit_and_continue(lpamd):
     m, n, seed = 120, 300, 7
     dt = lo.DenseTableau.synthetic(m, n, seed)
