@@ -167,7 +167,7 @@ int lpamd_poll(lpamd_engine* eng, int32_t* result);
  * The reference's other tableau algorithm, `solver <file> revised_simplex_tableau`
  * (reference solver.cc:139-144): the tableau stays as uploaded and a dense basis
  * inverse is carried along.  The handle owns a row-major copy of the tableau,
- * the inverse and its transpose, and all vectors; the loop runs on the device. */
+ * the inverse (stored transposed) and all vectors; the loop runs on the device. */
 typedef struct lpamd_rev_engine lpamd_rev_engine;
 /* m constraint rows, N variable columns (right-hand side at column N).
  * hip_stream as in lpamd_create.  Device memory is taken at upload time. */
@@ -198,7 +198,7 @@ int lpamd_rev_pivot_count(lpamd_rev_engine* eng, int64_t* n);
 /* (entering column, leaving basis position) of every pivot so far */
 int lpamd_rev_trace(lpamd_rev_engine* eng, int64_t* entering, int64_t* leaving_pos, int64_t cap, int64_t* n);
 /* Debug/test access; any pointer may be NULL.  Binv, BinvT: m x m row-major
- * (basis_inverse of the reference and its transpose); xB = basic_feasible_solution,
+ * (basis_inverse of the reference and its transpose, the form the engine stores); xB = basic_feasible_solution,
  * cB = basis_coeff, basis = basis_indices (reference lp.h:281-284). */
 int lpamd_rev_read_state(lpamd_rev_engine* eng, double* Binv, double* BinvT, double* xB, double* cB, int64_t* basis);
 
