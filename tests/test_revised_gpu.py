@@ -125,6 +125,46 @@ def test_revised_wide_tableau_and_many_rows(lpamd):
         del rt, BinvT
 
 
+@pytest.mark.parametrize("m,n,seed", [(1, 1, 1), (1, 100, 2), (100, 1, 3), (513, 3, 4), (2, 1100, 5), (63, 64, 6), (1025, 17, 7)])
+def test_revised_extreme_shapes(lpamd, m, n, seed):
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    rt = lo.RevisedTableau(dt.T, dt.obj, dt.is_basic, n + m, False)
+    want = rt.solve()
+    eng = lpamd.RevisedTableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    res, npiv = eng.solve()
+    assert res == want and npiv == rt.n_pivots
+    assert eng.trace() == rt.trace()
+    assert_same_state(eng, rt)
+    eng.close()
+
+
+def test_revised_full_size_properties(lpamd):
+    """m=32768 n=65536 (the benchmark's size): no oracle run at this size, so size-independent
+    properties: the run is deterministic, the basic solution stays feasible, every entering
+    column was non-basic and every basis position holds a distinct column."""
+    m, n, seed, piv = 32768, 65536, 1, 6
+    runs = []
+    for _ in range(2):
+        eng = lpamd.RevisedTableauEngine(m, n + m)
+        eng.fill_synthetic(n, seed)
+        res, npiv = eng.solve(max_pivots=piv)
+        assert res == lpamd.LIMIT and npiv == piv
+        _, _, xB, cB, basis = eng.read_state(inverse=False, transposed=False)
+        runs.append((eng.trace(), xB.copy(), basis.copy()))
+        eng.close()
+    assert runs[0][0] == runs[1][0]
+    assert np.array_equal(bits(runs[0][1]), bits(runs[1][1])) and np.array_equal(runs[0][2], runs[1][2])
+    trace, xB, basis = runs[0]
+    assert (xB >= 0).all()
+    assert len(set(basis.tolist())) == m
+    entered = [e for e, _ in trace]
+    assert all(0 <= e < n for e in entered)          # only structural columns carry a cost
+    for e, l in trace:
+        assert 0 <= l < m
+    assert set(basis.tolist()) - set(range(n, n + m)) <= set(entered)   # structural columns got in through a pivot
+
+
 def test_revised_pivot_limit_and_continue(lpamd):
     m, n, seed = 120, 300, 7
     dt = lo.DenseTableau.synthetic(m, n, seed)
