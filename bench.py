@@ -29,6 +29,13 @@ CONFIGS = {
     "synthetic_m32768_n65536": (32768, 65536),
     "synthetic_m65536_n262144": (65536, 262144),
     "synthetic_m1024_n2048": (1024, 2048),     # quick self-test size
+    # shape studies of the update kernel (same dense bytes, different column length)
+    "synthetic_m65536_n65536": (65536, 65536),
+    "synthetic_m32768_n131072": (32768, 131072),
+    "synthetic_m16384_n131072": (16384, 131072),
+    "synthetic_m131072_n16384": (131072, 16384),
+    "synthetic_m65536_n131072": (65536, 131072),
+    "synthetic_m65536_n196608": (65536, 196608),
 }
 DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak

@@ -66,7 +66,9 @@ struct lpamd_engine {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   // device memory
-  double* T = nullptr;
+  Tab T{};                  // two buffers: even / odd local columns
+  int64_t half_cols[2] = {0, 0};
+  bool placement_split = false;   // the halves were measured to lie in different HBM placement classes
   double* obj = nullptr;
   uint8_t* is_basic = nullptr;
   int64_t* basis = nullptr;
@@ -129,6 +131,106 @@ int ensure_trace(lpamd_engine* e, int64_t need) {
   }
   e->trace = nt;
   e->trace_cap = cap;
+  return LPAMD_OK;
+}
+
+int check_launch(const char* what);
+
+// ---- tableau allocation with HBM placement ------------------------------------
+// Measured on MI355X (scripts/placement_microbench.hip, profiles/): the address space of
+// the HBM falls into placement classes of 32 GiB units, and a read-modify-write stream whose
+// working set lies inside one class sustains about 5.4 TB/s against 6.4 TB/s when it spans
+// two.  Where hipMalloc puts a buffer cannot be chosen, but it can be measured: the shard is
+// kept as two buffers (even / odd local columns, which the update touches at the same
+// time), and the second one is re-allocated, with the rejected candidates held back as
+// spacers, until a short probe shows that the pair streams faster than the first buffer
+// alone.  Shards of 64 GiB and more span classes anyway; shards that fit the Infinity Cache
+// do not care.  LPAMD_PLACEMENT=0 takes the first allocation.
+__global__ __launch_bounds__(256, 2) void k_placement_probe(double2* __restrict__ a, double2* __restrict__ b, long chunks_per_side) {
+  for (long c = blockIdx.x; c < 2 * chunks_per_side; c += gridDim.x) {
+    double2* p = (c & 1 ? b : a) + (c >> 1) * 4096 + threadIdx.x;   // 64 KiB chunks, alternating sides
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      v[u].x = __builtin_nontemporal_load(&p[u * 256].x);
+      v[u].y = __builtin_nontemporal_load(&p[u * 256].y);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      __builtin_nontemporal_store(v[u].x, &p[u * 256].x);
+      __builtin_nontemporal_store(v[u].y, &p[u * 256].y);
+    }
+  }
+}
+
+// milliseconds of one probe pass over `bytes_per_side` of each side
+int placement_probe_ms(lpamd_engine* e, double* a, double* b, size_t bytes_per_side, float* ms_out) {
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  const long chunks = (long)(bytes_per_side / 65536);
+  hipLaunchKernelGGL(k_placement_probe, dim3(4096), dim3(256), 0, e->stream, (double2*)a, (double2*)b, chunks);
+  HIP_TRY(hipEventRecord(e0, e->stream));
+  for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_placement_probe, dim3(4096), dim3(256), 0, e->stream, (double2*)a, (double2*)b, chunks);
+  HIP_TRY(hipEventRecord(e1, e->stream));
+  HIP_TRY(hipEventSynchronize(e1));
+  HIP_TRY(hipEventElapsedTime(ms_out, e0, e1));
+  *ms_out /= 3;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return check_launch("k_placement_probe");
+}
+
+int allocate_tableau(lpamd_engine* e) {
+  e->T.lda = e->sh.lda;
+  e->half_cols[0] = (e->ncl + 1) / 2;
+  e->half_cols[1] = e->ncl / 2;
+  size_t bytes[2];
+  for (int h = 0; h < 2; h++) bytes[h] = sizeof(double) * (size_t)e->sh.lda * (size_t)e->half_cols[h];
+  hipError_t err = hipMalloc(&e->T.half[0], bytes[0]);
+  if (err != hipSuccess)
+    return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB for the tableau shard failed: %s", bytes[0] / 1e9, hipGetErrorString(err));
+  if (bytes[1] == 0) return LPAMD_OK;
+  bool probe = bytes[1] >= ((size_t)1 << 30) && bytes[1] < ((size_t)32 << 30);
+  if (const char* env = getenv("LPAMD_PLACEMENT")) probe = probe && atoi(env) != 0;
+  std::vector<double*> spacers;
+  double* chosen = nullptr;
+  if (probe) {
+    const size_t side = (size_t)512 << 20;   // 512 MiB per side: beyond the 256 MiB Infinity Cache
+    float alone = 0.f;
+    LP_TRY(placement_probe_ms(e, e->T.half[0], e->T.half[0] + side / sizeof(double), side, &alone));
+    // Every rejected candidate stays allocated, so the next one lands further on; small shards
+    // add a spacer so that an attempt advances by at least 12 GB of the 32 GiB units.
+    const size_t step = (size_t)12 << 30;
+    for (int attempt = 0; attempt < 16 && !chosen; attempt++) {
+      double* cand = nullptr;
+      if (hipMalloc(&cand, bytes[1]) != hipSuccess) { (void)hipGetLastError(); break; }
+      float pair = 0.f;
+      const int rc = placement_probe_ms(e, e->T.half[0], cand, side, &pair);
+      if (rc != LPAMD_OK) { (void)hipFree(cand); for (double* sp : spacers) (void)hipFree(sp); return rc; }
+      if (getenv("LPAMD_PLACEMENT_VERBOSE"))
+        fprintf(stderr, "lpamd placement: attempt %d, %.2f GB halves, probe alone %.3f ms, pair %.3f ms\n", attempt, bytes[1] / 1e9, alone, pair);
+      if (pair < 0.93f * alone) { chosen = cand; e->placement_split = true; break; }
+      spacers.push_back(cand);
+      if (bytes[1] < step) {
+        double* extra = nullptr;
+        if (hipMalloc(&extra, step - bytes[1]) == hipSuccess) spacers.push_back(extra);
+        else { (void)hipGetLastError(); break; }
+      }
+    }
+    if (!chosen && !spacers.empty()) {   // no better placement found: keep the first candidate
+      chosen = spacers.front();
+      spacers.erase(spacers.begin());
+    }
+    for (double* sp : spacers) (void)hipFree(sp);
+  }
+  if (!chosen) {
+    err = hipMalloc(&chosen, bytes[1]);
+    if (err != hipSuccess)
+      return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB for the tableau shard failed: %s", bytes[1] / 1e9, hipGetErrorString(err));
+  }
+  e->T.half[1] = chosen;
   return LPAMD_OK;
 }
 
@@ -326,7 +428,7 @@ int read_local(const lpamd_engine* e, const void* src, void* dst, size_t bytes) 
 
 int gather_row_host(const lpamd_engine* e, int64_t r, std::vector<double>& row_local) {
   row_local.resize(e->ncl);
-  hipLaunchKernelGGL(k_gather_row, dim3((e->ncl + 255) / 256), dim3(256), 0, e->stream, e->T, e->sh.lda, e->ncl, r, e->rowp);
+  hipLaunchKernelGGL(k_gather_row, dim3((e->ncl + 255) / 256), dim3(256), 0, e->stream, e->T, e->ncl, r, e->rowp);
   LP_TRY(check_launch("k_gather_row"));
   return read_local(e, e->rowp, row_local.data(), sizeof(double) * e->ncl);
 }
@@ -409,10 +511,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
   }
-  const size_t tbytes = sizeof(double) * (size_t)e->sh.lda * (size_t)e->ncl;
-  hipError_t err = hipMalloc(&e->T, tbytes);
-  if (err != hipSuccess)
-    return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB for the tableau shard failed: %s", tbytes / 1e9, hipGetErrorString(err));
+  LP_TRY(allocate_tableau(e));
   HIP_TRY(hipMalloc(&e->obj, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->is_basic, e->ncl));
   HIP_TRY(hipMalloc(&e->basis, sizeof(int64_t) * m));
@@ -448,7 +547,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T, e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->part_v, e->part_i, e->st, e->trace};
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->part_v, e->part_i, e->st, e->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -460,11 +559,12 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
   CHECK_ENGINE(e);
   const Shape& sh = e->sh;
   if (!T || !obj || !is_basic || ld < sh.m) return set_err(LPAMD_E_ARG, "upload: null buffer or ld < m");
-  std::vector<double> hT((size_t)sh.lda * e->ncl, 0.0), hobj(e->ncl, 0.0);
+  std::vector<double> hT[2], hobj(e->ncl, 0.0);
+  for (int h = 0; h < 2; h++) hT[h].assign((size_t)sh.lda * e->half_cols[h], 0.0);
   std::vector<uint8_t> hb(e->ncl, 0);
   for (int64_t l = 0; l < e->ncl; l++) {
     const int64_t g = global_of(e, l);
-    std::memcpy(&hT[(size_t)l * sh.lda], T + g * ld, sizeof(double) * sh.m);
+    std::memcpy(&hT[l & 1][(size_t)(l >> 1) * sh.lda], T + g * ld, sizeof(double) * sh.m);
     hobj[l] = obj[g];
     hb[l] = (g == sh.N || g == sh.N + 1) ? 0 : (is_basic[g] ? 1 : 0);
   }
@@ -477,7 +577,9 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
     for (int64_t i = 0; i < sh.m; i++)
       if (!h_is_zero(T[g * ld + i])) { basis[i] = g; break; }
   }
-  HIP_TRY(hipMemcpyAsync(e->T, hT.data(), sizeof(double) * hT.size(), hipMemcpyHostToDevice, e->stream));
+  for (int h = 0; h < 2; h++)
+    if (!hT[h].empty())
+      HIP_TRY(hipMemcpyAsync(e->T.half[h], hT[h].data(), sizeof(double) * hT[h].size(), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->obj, hobj.data(), sizeof(double) * e->ncl, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->is_basic, hb.data(), e->ncl, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->basis, basis.data(), sizeof(int64_t) * sh.m, hipMemcpyHostToDevice, e->stream));
@@ -508,10 +610,13 @@ int lpamd_download(const lpamd_engine* e, double* T, int64_t ld, double* obj, ui
   const Shape& sh = e->sh;
   if (T) {
     if (ld < sh.m) return set_err(LPAMD_E_ARG, "download: ld < m");
-    std::vector<double> hT((size_t)sh.lda * e->ncl);
-    LP_TRY(read_local(e, e->T, hT.data(), sizeof(double) * hT.size()));
-    for (int64_t l = 0; l < e->ncl; l++)
-      std::memcpy(T + global_of(e, l) * ld, &hT[(size_t)l * sh.lda], sizeof(double) * sh.m);
+    for (int h = 0; h < 2; h++) {
+      if (e->half_cols[h] == 0) continue;
+      std::vector<double> hT((size_t)sh.lda * e->half_cols[h]);
+      LP_TRY(read_local(e, e->T.half[h], hT.data(), sizeof(double) * hT.size()));
+      for (int64_t l = h; l < e->ncl; l += 2)
+        std::memcpy(T + global_of(e, l) * ld, &hT[(size_t)(l >> 1) * sh.lda], sizeof(double) * sh.m);
+    }
   }
   if (obj) {
     std::vector<double> h(e->ncl);
@@ -530,7 +635,7 @@ int lpamd_read_column(const lpamd_engine* e, int64_t col, double* out) {
   CHECK_LOADED(e);
   if (col < 0 || col > e->sh.N + 1 || !out) return set_err(LPAMD_E_ARG, "read_column: bad column %lld", (long long)col);
   if (!owns(e, col)) return set_err(LPAMD_E_ARG, "read_column: column %lld lives on another rank", (long long)col);
-  return read_local(e, e->T + local_of(e, col) * e->sh.lda, out, sizeof(double) * e->sh.m);
+  return read_local(e, e->T.col(local_of(e, col)), out, sizeof(double) * e->sh.m);
 }
 
 int lpamd_read_row(const lpamd_engine* e, int64_t row, double* out) {
@@ -563,7 +668,7 @@ int lpamd_need_init(lpamd_engine* e, int32_t* out) {
   CHECK_LOADED(e);
   if (!out) return set_err(LPAMD_E_ARG, "need_init: null");
   std::vector<double> rhs(e->sh.m);
-  LP_TRY(read_local(e, e->T + (int64_t)e->sh.nloc * e->sh.lda, rhs.data(), sizeof(double) * e->sh.m));
+  LP_TRY(read_local(e, e->T.col(e->sh.nloc), rhs.data(), sizeof(double) * e->sh.m));
   *out = 0;
   for (double b : rhs)
     if (h_is_neg(b)) { *out = 1; break; }
@@ -673,7 +778,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   LP_TRY(lpamd_write_objective(e, tmp.data()));
   const uint8_t zero8 = 0;
   HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));   // :71
-  hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T + local_of(e, A) * sh.lda, m, 1.0);  // :82-86
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T.col(local_of(e, A)), m, 1.0);  // :82-86
   LP_TRY(check_launch("k_fill"));
   LP_TRY(invalidate_pr(e));
   LP_TRY(lpamd_read_column(e, N, col.data()));
@@ -720,7 +825,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
     HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));
     LP_TRY(lpamd_download(e, nullptr, 0, nullptr, basic.data()));
   }
-  hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T + local_of(e, A) * sh.lda, m, 0.0);  // :143
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T.col(local_of(e, A)), m, 0.0);  // :143
   LP_TRY(check_launch("k_fill"));
   LP_TRY(invalidate_pr(e));
   saved[A] = 0.0;
@@ -929,7 +1034,7 @@ int lpamd_export_column(lpamd_engine* e, int64_t col, void* xbuf_dev) {
   CHECK_LOADED(e);
   if (!xbuf_dev || col < 0 || col > e->sh.N + 1 || col == e->sh.N) return set_err(LPAMD_E_ARG, "export_column: bad arguments");
   if (!owns(e, col)) return set_err(LPAMD_E_ARG, "export_column: column %lld lives on another rank", (long long)col);
-  HIP_TRY(hipMemcpyAsync(xbuf_dev, e->T + local_of(e, col) * e->sh.lda, sizeof(double) * e->sh.lda, hipMemcpyDeviceToDevice, e->stream));
+  HIP_TRY(hipMemcpyAsync(xbuf_dev, e->T.col(local_of(e, col)), sizeof(double) * e->sh.lda, hipMemcpyDeviceToDevice, e->stream));
   return LPAMD_OK;
 }
 

@@ -8,7 +8,9 @@
 //
 // Data layout (per engine / GPU):
 //   T        column-major fp64, leading dimension lda (multiple of 512 rows,
-//            padding rows are zero and stay zero), ncl = nloc + 1 columns:
+//            padding rows are zero and stay zero), ncl = nloc + 1 columns, kept as
+//            two buffers (even / odd local columns, struct Tab) so that the halves
+//            can sit in different HBM placement classes (see lpamd_engine.hip):
 //            local column l < nloc holds the variable column whose ordinal is
 //            l * world + rank; local column nloc is the replica of the
 //            right-hand-side column.
@@ -48,6 +50,13 @@ struct PivotState {  // device resident, one per engine
   double a, ce, f, g;
   int32_t n_active;  // local columns whose pivot-row entry is non-zero
   int32_t pad1;
+};
+
+// The tableau shard: local column l lives in half[l & 1] at column slot l >> 1.
+struct Tab {
+  double* half[2];
+  int64_t lda;
+  __host__ __device__ __forceinline__ double* col(int64_t l) const { return half[l & 1] + (l >> 1) * lda; }
 };
 
 struct Shape {
@@ -195,7 +204,7 @@ __device__ __forceinline__ double wave_min_all(double v) {
 }
 
 __global__ __launch_bounds__(256) void k_pr_columns(
-    const double* __restrict__ T, const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
+    Tab T, const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
     Shape sh, const PivotState* __restrict__ st, double* __restrict__ cmin, int64_t* __restrict__ crow,
     const int64_t* __restrict__ pr_stamp) {
   __shared__ double s_v[256 / kWave];
@@ -207,8 +216,8 @@ __global__ __launch_bounds__(256) void k_pr_columns(
     return;
   }
   if (pr_stamp[l] == st->iter) return;   // the last update already left this column's minimum ratio
-  const double2* __restrict__ col = reinterpret_cast<const double2*>(T + (int64_t)l * sh.lda);
-  const double2* __restrict__ rhs = reinterpret_cast<const double2*>(T + (int64_t)sh.nloc * sh.lda);
+  const double2* __restrict__ col = reinterpret_cast<const double2*>(T.col(l));
+  const double2* __restrict__ rhs = reinterpret_cast<const double2*>(T.col(sh.nloc));
   const int n_vec = (int)(sh.lda / 2);           // multiple of 256
   double bv = DBL_MAX, bound = DBL_MAX;
   int64_t bi = -1;
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pr_fold(
 // (single-GPU loop); otherwise it comes with the candidate record.
 template <bool kFoldPrice>
 __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
-    const double* __restrict__ T, Shape sh, PivotState* __restrict__ st,
+    Tab T, Shape sh, PivotState* __restrict__ st,
     const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
     Candidate* __restrict__ cand, const double* __restrict__ xcol,
     double* __restrict__ rv, int64_t* __restrict__ ri) {
@@ -328,8 +337,8 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
     e = cand->gcol;
     if (e < 0) { if (lead) st->status = ST_SOLVED; return; }
   }
-  const double* __restrict__ col = xcol ? xcol : T + (ordinal_of(e, sh.N) / sh.world) * sh.lda;
-  const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+  const double* __restrict__ col = xcol ? xcol : T.col(ordinal_of(e, sh.N) / sh.world);
+  const double* __restrict__ rhs = T.col(sh.nloc);
   double bv = DBL_MAX;
   int64_t bi = -1;
   for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
@@ -359,7 +368,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
 // separate pricing launch).  The first column workgroup records the pivot.
 template <bool kFindRow>
 __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
-    const double* __restrict__ T, Shape sh, const Candidate* __restrict__ cand, const double* __restrict__ xcol,
+    Tab T, Shape sh, const Candidate* __restrict__ cand, const double* __restrict__ xcol,
     const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
     int64_t d_override, PivotState* __restrict__ st, double* __restrict__ colp,
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
@@ -380,12 +389,12 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
   }
   if (r < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
   const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
-  const double* __restrict__ col = xcol ? xcol : T + (eo / sh.world) * sh.lda;
+  const double* __restrict__ col = xcol ? xcol : T.col(eo / sh.world);
   const double a = col[r];
   const double f = -1.0 / a;                         // lp_simplex_tableau.cc:40
   const double g = __dmul_rn(c.ce, f);               // lp_simplex_tableau.cc:34-35
   if ((int)blockIdx.x < n_row_blocks) {
-    const double* __restrict__ rhs = T + (int64_t)sh.nloc * sh.lda;
+    const double* __restrict__ rhs = T.col(sh.nloc);
     const double rp_rhs = __dmul_rn(rhs[r], f);
     for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
       const double cpi = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
@@ -408,7 +417,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
     const int l = l0 + threadIdx.x;
     bool act = false;
     if (l < ncl) {
-      const double t = T[(int64_t)l * sh.lda + r];
+      const double t = T.col(l)[r];
       const double rp = __dmul_rn(t, f);
       double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g)));   // :36
       if (l == l_e) o = 0.0;                                     // :37
@@ -487,7 +496,7 @@ __device__ __forceinline__ double2 rank1(double2 t, double2 c, double rj) {
 // (b' = rhs_next), which saves the separate 8*m*n read pass of k_pr_columns.
 template <int kUnroll, bool kNT, bool kPreC, bool kFusePR>
 __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register budget for 2*kUnroll 16-byte loads in flight
-    double* __restrict__ T, int64_t lda, const double* __restrict__ colp,
+    Tab T, int64_t lda, const double* __restrict__ colp,
     const double* __restrict__ rowp, const int32_t* __restrict__ active,
     const PivotState* __restrict__ st, Shape sh, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
     const double* __restrict__ rhs_next, const uint8_t* __restrict__ cand_next,
@@ -513,7 +522,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   for (int k = blockIdx.x; k < n_active; k += gridDim.x) {
     const int l = active[k];
     const double rj = rowp[l];
-    double2* __restrict__ p = reinterpret_cast<double2*>(T + (int64_t)l * lda);
+    double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l));
     const bool price = kFusePR && l < sh.nloc && cand_next[l] != 0;   // uniform over the workgroup
     double bv = DBL_MAX, bound = DBL_MAX;
     int64_t bi = -1;
@@ -595,7 +604,7 @@ __global__ __launch_bounds__(kWave) void k_fold_candidates(
 // to zeros) then delivers the exact column to every rank without a data-dependent
 // broadcast root.
 __global__ __launch_bounds__(256) void k_export_or_zero(
-    const double* __restrict__ T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand,
+    Tab T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand,
     double* __restrict__ xbuf) {
   if (st->status != ST_RUNNING) return;
   const int64_t e = cand->gcol;
@@ -604,15 +613,15 @@ __global__ __launch_bounds__(256) void k_export_or_zero(
   double v = 0.0;
   if (e >= 0) {
     const int64_t eo = ordinal_of(e, sh.N);
-    if (eo % sh.world == sh.rank) v = T[(eo / sh.world) * sh.lda + i];
+    if (eo % sh.world == sh.rank) v = T.col(eo / sh.world)[i];
   }
   xbuf[i] = v;
 }
 
 // --------------------------------------------------------------- utilities
-__global__ void k_gather_row(const double* __restrict__ T, int64_t lda, int32_t ncl, int64_t r, double* __restrict__ out) {
+__global__ void k_gather_row(Tab T, int32_t ncl, int64_t r, double* __restrict__ out) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
-  if (l < ncl) out[l] = T[(int64_t)l * lda + r];
+  if (l < ncl) out[l] = T.col(l)[r];
 }
 
 __global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
@@ -623,19 +632,19 @@ __global__ void k_fill(double* __restrict__ p, int64_t n, double v) {
 // GetTableauSimplexSolution, per-column part (reference lp_simplex_tableau.cc:388-399):
 // for a basic column the LAST row with a non-zero entry defines x = -b_i / T_ij.
 __global__ __launch_bounds__(256) void k_column_values(
-    const double* __restrict__ T, const uint8_t* __restrict__ is_basic, Shape sh, double* __restrict__ x) {
+    Tab T, const uint8_t* __restrict__ is_basic, Shape sh, double* __restrict__ x) {
   __shared__ double s_v[256 / kWave];
   __shared__ int64_t s_i[256 / kWave];
   const int l = blockIdx.x;
   if (!is_basic[l]) { if (threadIdx.x == 0) x[l] = 0.0; return; }
-  const double* __restrict__ col = T + (int64_t)l * sh.lda;
+  const double* __restrict__ col = T.col(l);
   double bv = 0.0;
   int64_t bi = -1;
   for (int64_t i = threadIdx.x; i < sh.m; i += 256)
     if (!is_zero(col[i])) { bv = (double)i; bi = i; }
   block_arg<true, 256>(bv, bi, s_v, s_i);
   if (threadIdx.x == 0) {
-    const double* rhs = T + (int64_t)sh.nloc * sh.lda;
+    const double* rhs = T.col(sh.nloc);
     x[l] = bi < 0 ? 0.0 : -rhs[bi] / col[bi];
   }
 }
@@ -665,12 +674,12 @@ __host__ __device__ __forceinline__ double synth_entry(uint64_t seed, int64_t m,
 }
 
 __global__ __launch_bounds__(256) void k_fill_synthetic(
-    double* __restrict__ T, double* __restrict__ obj, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
+    Tab T, double* __restrict__ obj, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
     Shape sh, int64_t n, uint64_t seed) {
   const int l = blockIdx.x;                       // local column, nloc = RHS replica
   const int64_t g = l < sh.nloc ? gcol_of((int64_t)l * sh.world + sh.rank, sh.N) : sh.N;
   const int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x;
-  if (i < sh.lda) T[(int64_t)l * sh.lda + i] = i < sh.m ? synth_entry(seed, sh.m, n, i, g) : 0.0;
+  if (i < sh.lda) T.col(l)[i] = i < sh.m ? synth_entry(seed, sh.m, n, i, g) : 0.0;
   if (i == 0) {
     obj[l] = synth_entry(seed, sh.m, n, sh.m, g);
     is_basic[l] = (l < sh.nloc && g >= n && g < n + sh.m) ? 1 : 0;
