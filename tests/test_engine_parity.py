@@ -151,3 +151,30 @@ def test_extreme_shapes(lpamd, m, n):
         assert eng.trace() == dt.trace()
         assert_same_tableau(eng, dt)
     eng.close()
+
+
+@pytest.mark.parametrize("knobs", [
+    {"LPAMD_UPDATE_NT": "1", "LPAMD_UPDATE_PREC": "0", "LPAMD_UPDATE_PREC_FUSED": "0"},
+    {"LPAMD_UPDATE_NT": "1", "LPAMD_UPDATE_PREC": "1", "LPAMD_UPDATE_PREC_FUSED": "1"},
+    {"LPAMD_UPDATE_NT": "0", "LPAMD_UPDATE_PREC": "0", "LPAMD_UPDATE_PREC_FUSED": "0"},
+    {"LPAMD_FUSE_PR": "0"},
+    {"LPAMD_UPDATE_UNROLL": "1"},
+    {"LPAMD_UPDATE_UNROLL": "4", "LPAMD_UPDATE_GRID": "7"},
+    {"LPAMD_PLACEMENT": "0"},
+])
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+def test_update_kernel_variants_are_bit_identical(lpamd, monkeypatch, knobs, strategy):
+    """Every variant of the update kernel the engine may pick by shard size (cache policy, place of
+    the col' load, fused pricing, unroll depth, grid) forced on one LP the oracle solves fully."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    m, n, seed = 1100, 700, 21
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    want = dt.solve(lo.STRATEGY[strategy])
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    res, npiv = eng.solve(lpamd.STRATEGY[strategy])
+    assert res == want == lpamd.SOLVED and npiv == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
