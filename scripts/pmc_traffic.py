@@ -1,0 +1,47 @@
+"""Reduces two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; one run each, as the hardware
+cannot hold both with their derived counters) to HBM bytes per k_update launch.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline
+    python scripts/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write synthetic_m32768_n65536 > profiles/roundN/pmc_hbm_traffic_<config>.json
+
+FETCH_SIZE / WRITE_SIZE count KiB; on gfx950 FETCH_SIZE reports half of the bytes of wide
+coalesced reads and is doubled."""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_launch(directory, counter):
+    vals = []
+    name = None
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == counter and "k_update" in row["Kernel_Name"]:
+                vals.append(float(row["Counter_Value"]))
+                name = row["Kernel_Name"].split("(")[0]
+    return (sum(vals) / len(vals) if vals else None), len(vals), name
+
+
+def main():
+    fetch_dir, write_dir, config = sys.argv[1:4]
+    m, n = (int(x[1:]) for x in config.split("_")[1:3])
+    f, nf, name = per_launch(fetch_dir, "FETCH_SIZE")
+    w, nw, _ = per_launch(write_dir, "WRITE_SIZE")
+    read_b, write_b = 2.0 * f * 1024, w * 1024
+    algo = 16.0 * m * (n + 2)
+    print(json.dumps({
+        "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline (one pass per counter)",
+        "config": config, "kernel": name,
+        "note": "FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read, so it is doubled",
+        "FETCH_SIZE_avg_KiB_per_launch": f, "FETCH_SIZE_launches": nf,
+        "WRITE_SIZE_avg_KiB_per_launch": w, "WRITE_SIZE_launches": nw,
+        "read_bytes_per_launch_corrected": read_b, "write_bytes_per_launch": write_b,
+        "traffic_bytes_per_launch": read_b + write_b, "algorithmic_bytes_per_launch": algo,
+        "traffic_over_algorithmic": (read_b + write_b) / algo}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
