@@ -24,7 +24,6 @@ struct lpamd_rev_engine {
   double* mu = nullptr;
   double* colbuf = nullptr;
   double* scaled = nullptr;
-  int32_t* idx_col = nullptr;   // rows of the non-zero entries of colbuf
   int32_t* idx_upd = nullptr;   // rows of BinvT the pending update visits
   uint8_t* touched = nullptr;   // one byte per row of BinvT: the pending update visits it
   RevState* st = nullptr;
@@ -42,7 +41,8 @@ struct lpamd_rev_engine {
   // LPAMD_REV_ROWDOT_ROWS=16|64, LPAMD_REV_UPDATE_UNROLL=4|16
   // LPAMD_REV_SPLIT=0|1: strided gathers inside the single-workgroup selection kernels / as
   // chip-wide kernels of their own (default: by size)
-  int force_vec = 0, force_rowdot_rows = 0, force_update_unroll = 0, force_split = -1;
+  // LPAMD_REV_TILE=0|16|64: column products one lane per output / through LDS tiles 16 or 64 outputs wide
+  int force_vec = 0, force_rowdot_rows = 0, force_update_unroll = 0, force_split = -1, force_tile = -1;
   bool split() const { return force_split >= 0 ? force_split != 0 : sh.m > 8192; }
 };
 
@@ -56,13 +56,13 @@ namespace {
 
 void rev_free(lpamd_rev_engine* h) {
   void* ptrs[] = {h->Trm, h->BinvT, h->obj, h->cost, h->is_basic, h->negate, h->basis, h->rows, h->xB,
-                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_col, h->idx_upd, h->touched, h->st, h->trace};
+                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_upd, h->touched, h->st, h->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->Trm = h->BinvT = h->obj = h->cost = h->xB = h->cB = h->pvec = h->mu = h->colbuf = h->scaled = nullptr;
   h->is_basic = h->negate = h->touched = nullptr;
   h->basis = h->rows = h->trace = nullptr;
-  h->idx_col = h->idx_upd = nullptr;
+  h->idx_upd = nullptr;
   h->st = nullptr;
   h->trace_cap = 0;
 }
@@ -86,7 +86,6 @@ int rev_allocate(lpamd_rev_engine* h, int64_t W) {
   HIP_TRY(hipMalloc(&h->negate, sh.ldb));
   HIP_TRY(hipMalloc(&h->basis, sizeof(int64_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->rows, sizeof(int64_t) * sh.ldb));
-  HIP_TRY(hipMalloc(&h->idx_col, sizeof(int32_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->idx_upd, sizeof(int32_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->touched, sh.ldb));
   double** vecs[] = {&h->xB, &h->cB, &h->pvec, &h->mu, &h->colbuf, &h->scaled};
@@ -140,37 +139,32 @@ int rev_upload_obj(lpamd_rev_engine* h) {
   return LPAMD_OK;
 }
 
-// out[0..ncols) = sum over rows of coef[r] * M[r][.] (+ base with the zero drop when it is given);
-// idx/count (device) restrict the sum to the listed rows.
-int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, const int32_t* idx, const int32_t* count,
-               int64_t ncols, const double* coef, const double* base, double* out) {
-  // Two columns (16 bytes) per lane once that still leaves a wavefront per CU: measured 5.3 vs
-  // 4.9 TB/s on the 32768-wide inverse.  The sum itself is sequential per lane, so the loads in
-  // flight are what hides the HBM latency.
+// out[0..ncols) = sum over rows of coef[r] * M[r][.] (+ base with the zero drop when it is given)
+int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, int64_t ncols, const double* coef,
+               const double* base, double* out) {
+  // LDS-tiled product: 64 outputs per workgroup once that fills the chip, 16 below.  Measured at
+  // m=32768 n=65536 with a dense coefficient vector: 2.87 / 1.18 ms against 3.58 / 1.49 ms for one
+  // lane per output (pricing / B^-1 column); at m=4096: 0.30 against 0.47 ms per pivot.
+  const int tile = h->force_tile >= 0 ? h->force_tile : (ncols >= 64 * 256 ? 64 : 16);
+  if (tile == 64 || tile == 16) {
+    const dim3 tgrid((unsigned)((ncols + tile - 1) / tile)), tblock(kRevThreads);
+#define LPAMD_REV_COLTILE(W, C) \
+  hipLaunchKernelGGL((k_rev_coltile<W, C>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out)
+    if (tile == 64) { if (base) LPAMD_REV_COLTILE(64, true); else LPAMD_REV_COLTILE(64, false); }
+    else { if (base) LPAMD_REV_COLTILE(16, true); else LPAMD_REV_COLTILE(16, false); }
+#undef LPAMD_REV_COLTILE
+    return check_launch("k_rev_coltile");
+  }
+  // one lane per output: two columns (16 bytes) per lane once that still leaves a wavefront per CU,
+  // one wavefront per workgroup on narrow outputs so that the lanes spread over all CUs
   const bool vec2 = h->force_vec ? h->force_vec == 2 : ncols >= 2 * 64 * 128;
-  // narrow outputs: one wavefront per workgroup, so that the lanes spread over all CUs
   const int threads = ncols / (vec2 ? 2 : 1) >= 512 * kRevThreads ? kRevThreads : kWave;
   const int64_t per_block = (int64_t)threads * (vec2 ? 2 : 1);
   const dim3 grid((unsigned)((ncols + per_block - 1) / per_block)), block(threads);
-#define LPAMD_REV_COLSUM(V, U, C, I) \
-  hipLaunchKernelGGL((k_rev_colsum<V, U, C, I>), grid, block, 0, h->stream, h->st, M, ld, nrows, idx, count, ncols, coef, base, out)
-#define LPAMD_REV_COLSUM_I(V, U, C)                     \
-  do {                                                  \
-    if (idx) LPAMD_REV_COLSUM(V, U, C, true);           \
-    else LPAMD_REV_COLSUM(V, U, C, false);              \
-  } while (0)
-  // one column per lane leaves few lanes on narrow outputs: 32 row loads in flight instead of 16
-  const bool deep = !vec2 && nrows >= 8192;
-  if (base) {
-    if (vec2) LPAMD_REV_COLSUM_I(2, 16, true);
-    else if (deep) LPAMD_REV_COLSUM_I(1, 32, true);
-    else LPAMD_REV_COLSUM_I(1, 16, true);
-  } else {
-    if (vec2) LPAMD_REV_COLSUM_I(2, 16, false);
-    else if (deep) LPAMD_REV_COLSUM_I(1, 32, false);
-    else LPAMD_REV_COLSUM_I(1, 16, false);
-  }
-#undef LPAMD_REV_COLSUM_I
+#define LPAMD_REV_COLSUM(V, C) \
+  hipLaunchKernelGGL((k_rev_colsum<V, 16, C>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out)
+  if (base) { if (vec2) LPAMD_REV_COLSUM(2, true); else LPAMD_REV_COLSUM(1, true); }
+  else { if (vec2) LPAMD_REV_COLSUM(2, false); else LPAMD_REV_COLSUM(1, false); }
 #undef LPAMD_REV_COLSUM
   return check_launch("k_rev_colsum");
 }
@@ -200,13 +194,12 @@ int rev_enqueue_update(lpamd_rev_engine* h) {
   return check_launch("k_rev_update");
 }
 
-// Entering column (pricing, or the first column with a non-zero probe entry), its copy in
-// colbuf and the list of its non-zero rows.
+// Entering column (pricing, or the first column with a non-zero probe entry) and its copy in colbuf.
 int rev_enqueue_entering(lpamd_rev_engine* h, bool first_nonzero, int64_t ncols_active) {
   const RevShape& sh = h->sh;
   const dim3 one(1), sel(kRevSelectThreads);
 #define LPAMD_REV_ENTER(F, G) \
-  hipLaunchKernelGGL((k_rev_select_entering<F, G>), one, sel, 0, h->stream, h->st, sh, ncols_active, h->cost, h->is_basic, h->Trm, h->colbuf, h->idx_col)
+  hipLaunchKernelGGL((k_rev_select_entering<F, G>), one, sel, 0, h->stream, h->st, sh, ncols_active, h->cost, h->is_basic, h->Trm, h->colbuf)
   if (!h->split()) {
     if (first_nonzero) LPAMD_REV_ENTER(true, true); else LPAMD_REV_ENTER(false, true);
     return check_launch("k_rev_select_entering");
@@ -216,17 +209,15 @@ int rev_enqueue_entering(lpamd_rev_engine* h, bool first_nonzero, int64_t ncols_
   LP_TRY(check_launch("k_rev_select_entering"));
   hipLaunchKernelGGL(k_rev_gather_wide, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
                      h->Trm, sh.ldw, sh.m, (int64_t)-1, h->colbuf);
-  LP_TRY(check_launch("k_rev_gather_wide"));
-  hipLaunchKernelGGL(k_rev_list_nonzero, one, sel, 0, h->stream, h->st, h->colbuf, sh.m, h->idx_col);
-  return check_launch("k_rev_list_nonzero");
+  return check_launch("k_rev_gather_wide");
 }
 
-// B^-1 * colbuf (over the listed non-zero rows of colbuf), ratio test (or the forced leaving
+// B^-1 * colbuf, ratio test (or the forced leaving
 // position), vector part of the pivot, rank-1 update.
 int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
   const RevShape& sh = h->sh;
   const dim3 one(1), sel(kRevSelectThreads);
-  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, h->idx_col, &h->st->n_col, sh.m, h->colbuf, nullptr, h->mu));
+  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, sh.m, h->colbuf, nullptr, h->mu));
   if (!h->split()) {
     hipLaunchKernelGGL((k_rev_select_leaving<true>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
                        h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap);
@@ -249,7 +240,7 @@ int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
 int rev_enqueue_iteration(lpamd_rev_engine* h, int64_t ncols_active) {
   const RevShape& sh = h->sh;
   LP_TRY(rev_rowdot(h));
-  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, nullptr, nullptr, ncols_active, h->pvec, h->obj, h->cost));
+  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost));
   LP_TRY(rev_enqueue_entering(h, false, ncols_active));
   return rev_enqueue_pivot_tail(h, -1);
 }
@@ -368,9 +359,7 @@ int rev_phase1(lpamd_rev_engine* h, int64_t max_pivots, int32_t* result) {
     hipLaunchKernelGGL(k_rev_gather_wide, dim3((unsigned)((m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
                        h->BinvT, sh.ldb, m, i, h->colbuf);
     LP_TRY(check_launch("k_rev_gather_wide"));
-    hipLaunchKernelGGL(k_rev_list_nonzero, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, h->colbuf, m, h->idx_col);
-    LP_TRY(check_launch("k_rev_list_nonzero"));
-    LP_TRY(rev_colsum(h, h->Trm, sh.ldw, m, h->idx_col, &h->st->n_col, W0, h->colbuf, nullptr, h->cost));
+    LP_TRY(rev_colsum(h, h->Trm, sh.ldw, m, W0, h->colbuf, nullptr, h->cost));
     LP_TRY(rev_enqueue_entering(h, true, W0));
     LP_TRY(rev_enqueue_pivot_tail(h, i));
     LP_TRY(rev_pull(h));
@@ -413,6 +402,7 @@ int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_str
   if (const char* env = getenv("LPAMD_REV_ROWDOT_ROWS")) h->force_rowdot_rows = atoi(env);
   if (const char* env = getenv("LPAMD_REV_UPDATE_UNROLL")) h->force_update_unroll = atoi(env);
   if (const char* env = getenv("LPAMD_REV_SPLIT")) h->force_split = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_TILE")) h->force_tile = atoi(env);
   *out = h;
   return LPAMD_OK;
 }

@@ -20,8 +20,7 @@
 //          non-zero, and c_B^T * B^-1 is a dot product along every row, done through
 //          LDS tiles so that the global loads stay coalesced.
 //   obj, cost  ldw doubles; xB, cB, pvec, mu, colbuf, scaled  ldb doubles;
-//   idx_col, idx_upd  ldb int32: compacted index lists (non-zero entries of the
-//   entering column; rows of BinvT the pending update has to touch).
+//   idx_upd  ldb int32: compacted list of the rows of BinvT the pending update has to touch.
 #pragma once
 #include "lpamd_kernels.hip.h"
 
@@ -35,8 +34,8 @@ struct RevState {      // device resident, one per revised engine
   int64_t e;           // entering column of the pivot in flight
   int64_t leaving;     // leaving basis position
   double ratio;
-  int32_t n_col;       // entries of idx_col
   int32_t n_upd;       // entries of idx_upd
+  int32_t pad0;
 };
 
 struct RevShape {
@@ -78,78 +77,132 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_w /* [kRevSele
   return res;
 }
 
-// Sequential sum of coef[r] * (p[r * ld], p[r * ld + 1]) over rows 0..n-1 (kIndexed: rows idx[0..n)),
-// kUnroll row loads in flight per lane.
-template <int kVec, int kUnroll, bool kIndexed>
-__device__ __forceinline__ void colsum_rows(const double* __restrict__ p, int64_t ld, int64_t n, const int32_t* __restrict__ idx,
-                                            const double* __restrict__ coef, double& a0, double& a1) {
-  int64_t t = 0;
-  for (; t + kUnroll <= n; t += kUnroll) {
-    int64_t r[kUnroll];
-#pragma unroll
-    for (int u = 0; u < kUnroll; u++) {
-      if constexpr (kIndexed) r[u] = idx[t + u]; else r[u] = t + u;
-    }
+// out[j] = sum over rows r (ascending) of coef[r] * M[r * ld + j]; with kCost the
+// result is flushz(base[j] + sum), the reduced cost of column j (reference
+// lp_revised_simplex_tableau.cc:237-238; Tableau::Times, :155 and :280).
+// One lane owns columns 2t and 2t+1 (kVec == 2) or column t (kVec == 1) and keeps kUnroll
+// row loads in flight; ld is even and covers the rounded-up column count, padding
+// entries are finite.  This is the plain form of the product; the engine runs the
+// LDS-tiled k_rev_coltile by default (LPAMD_REV_TILE=0 selects this one).
+template <int kVec, int kUnroll, bool kCost>
+__global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
+    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kVec;   // 64..256 lanes per workgroup
+  if (j >= ncols) return;
+  const double* __restrict__ p = M + j;
+  double a0 = 0.0, a1 = 0.0;
+  int64_t r = 0;
+  for (; r + kUnroll <= nrows; r += kUnroll) {
     if constexpr (kVec == 2) {
       double2 v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) v[u] = *reinterpret_cast<const double2*>(p + r[u] * ld);
+      for (int u = 0; u < kUnroll; u++) {
+        const double* q = p + (r + u) * ld;
+        v[u].x = __builtin_nontemporal_load(q);
+        v[u].y = __builtin_nontemporal_load(q + 1);
+      }
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
-        const double c = coef[r[u]];
+        const double c = coef[r + u];
         a0 = __dadd_rn(a0, __dmul_rn(c, v[u].x));
         a1 = __dadd_rn(a1, __dmul_rn(c, v[u].y));
       }
     } else {
       double v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) v[u] = p[r[u] * ld];
+      for (int u = 0; u < kUnroll; u++) v[u] = __builtin_nontemporal_load(p + (r + u) * ld);
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) a0 = __dadd_rn(a0, __dmul_rn(coef[r[u]], v[u]));
+      for (int u = 0; u < kUnroll; u++) a0 = __dadd_rn(a0, __dmul_rn(coef[r + u], v[u]));
     }
   }
-  for (; t < n; t++) {
-    int64_t r = t;
-    if constexpr (kIndexed) r = idx[t];
+  for (; r < nrows; r++) {
     const double c = coef[r];
-    if constexpr (kVec == 2) {
-      const double2 v = *reinterpret_cast<const double2*>(p + r * ld);
-      a0 = __dadd_rn(a0, __dmul_rn(c, v.x));
-      a1 = __dadd_rn(a1, __dmul_rn(c, v.y));
-    } else {
-      a0 = __dadd_rn(a0, __dmul_rn(c, p[r * ld]));
-    }
+    a0 = __dadd_rn(a0, __dmul_rn(c, p[r * ld]));
+    if constexpr (kVec == 2) a1 = __dadd_rn(a1, __dmul_rn(c, p[r * ld + 1]));
   }
-}
-
-// out[j] = sum over rows r (ascending) of coef[r] * M[r * ld + j]; with kCost the
-// result is flushz(base[j] + sum), the reduced cost of column j (reference
-// lp_revised_simplex_tableau.cc:237-238; Tableau::Times, :155 and :280).
-// kIndexed: idx[0..*count) lists the rows with a non-zero coefficient; the list is
-// used when it drops at least half of the rows (following it costs a dependent
-// scalar load per row), otherwise all rows are streamed.
-// One lane owns columns 2t and 2t+1 (kVec == 2) or column t (kVec == 1); ld is even
-// and covers the rounded-up column count, padding entries are finite.
-template <int kVec, int kUnroll, bool kCost, bool kIndexed>
-__global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
-    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, const int32_t* __restrict__ idx,
-    const int32_t* __restrict__ count, int64_t ncols, const double* __restrict__ coef, const double* __restrict__ base,
-    double* __restrict__ out) {
-  if (st->status != ST_RUNNING) return;
-  const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kVec;   // 64..256 lanes per workgroup
-  if (j >= ncols) return;
-  const double* __restrict__ p = M + j;
-  double a0 = 0.0, a1 = 0.0;
-  bool listed = false;
-  if constexpr (kIndexed) listed = 2 * (int64_t)*count <= nrows;
-  if (kIndexed && listed) colsum_rows<kVec, kUnroll, true>(p, ld, *count, idx, coef, a0, a1);
-  else colsum_rows<kVec, kUnroll, false>(p, ld, nrows, idx, coef, a0, a1);
   if constexpr (kCost) {
     a0 = flushz(__dadd_rn(base[j], a0));
     if (kVec == 2 && j + 1 < ncols) a1 = flushz(__dadd_rn(base[j + 1], a1));
   }
   out[j] = a0;
   if (kVec == 2 && j + 1 < ncols) out[j + 1] = a1;
+}
+
+// The same sum as k_rev_colsum, out[j] = sum_r coef[r] * M[r * ld + j] (+ base and zero drop with
+// kCost), staged through LDS: a workgroup owns kW adjacent outputs and sweeps the rows in chunks
+// of 4096 / kW; all 256 lanes load the chunk (16 bytes each, eight loads in flight) while kW lanes
+// of the first wavefront add it up in row order.  Against one-lane-per-output this puts 4 to 16
+// times more loads in flight per output, which is what narrow or short matrices need; chunks
+// whose coefficients are all zero are skipped.
+template <int kW, bool kCost>
+__global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
+    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out) {
+  constexpr int kH = 4096 / kW;                    // rows per chunk
+  constexpr int kRowsPerPass = 2 * kRevThreads / kW;
+  constexpr int kPasses = kH / kRowsPerPass;       // = 8
+  __shared__ double tile[kH * kW];
+  __shared__ double s_coef[kH];
+  if (st->status != ST_RUNNING) return;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int64_t j0 = (int64_t)blockIdx.x * kW;
+  const int lrow = tid / (kW / 2), lcol = (tid % (kW / 2)) * 2;
+  const int64_t nchunks = (nrows + kH - 1) / kH;
+  auto next_active = [&](int64_t c) {
+    for (; c < nchunks; c++) {
+      bool nz = false;
+      for (int q = lane; q < kH; q += kWave) {
+        const int64_t r = c * kH + q;
+        nz |= r < nrows && coef[r] != 0.0;
+      }
+      if (__ballot(nz) != 0) break;
+    }
+    return c;
+  };
+  double2 reg[kPasses];
+  double creg[(kH + kRevThreads - 1) / kRevThreads];
+  auto issue_loads = [&](int64_t c) {
+#pragma unroll
+    for (int q = 0; q < kPasses; q++) {
+      const int64_t gr = c * kH + q * kRowsPerPass + lrow;
+      const double* src = M + gr * ld + j0 + lcol;
+      if (gr < nrows && j0 + lcol < ld) {
+        reg[q].x = __builtin_nontemporal_load(src);
+        reg[q].y = __builtin_nontemporal_load(src + 1);
+      } else {
+        reg[q] = make_double2(0.0, 0.0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q * kRevThreads < kH; q++) {
+      const int64_t r = c * kH + q * kRevThreads + tid;
+      creg[q] = (q * kRevThreads + tid < kH && r < nrows) ? coef[r] : 0.0;
+    }
+  };
+  double acc = 0.0;
+  int64_t c = next_active(0);
+  if (c < nchunks) issue_loads(c);
+  while (c < nchunks) {
+    __syncthreads();   // the previous tile has been consumed
+#pragma unroll
+    for (int q = 0; q < kPasses; q++)
+      *reinterpret_cast<double2*>(tile + (q * kRowsPerPass + lrow) * kW + lcol) = reg[q];
+#pragma unroll
+    for (int q = 0; q * kRevThreads < kH; q++)
+      if (q * kRevThreads + tid < kH) s_coef[q * kRevThreads + tid] = creg[q];
+    __syncthreads();
+    const int64_t cn = next_active(c + 1);
+    if (cn < nchunks) issue_loads(cn);
+    if (tid < kW) {
+#pragma unroll 16
+      for (int rr = 0; rr < kH; rr++) acc = __dadd_rn(acc, __dmul_rn(s_coef[rr], tile[rr * kW + tid]));
+    }
+    c = cn;
+  }
+  const int64_t j = j0 + tid;
+  if (tid < kW && j < ncols) out[j] = kCost ? flushz(__dadd_rn(base[j], acc)) : acc;
 }
 
 // out[r] = sum_i coef[i] * M[r * ld + i], i ascending: a dot product along every row
@@ -221,29 +274,23 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
   if (tid < kR && r0 + tid < nrows) out[r0 + tid] = acc;
 }
 
-// colbuf[r] = M[r * ld + col] for this thread's run of rows [r_begin, r_end) and, over the whole
-// workgroup, the ascending list of the rows with a non-zero entry.  The strided loads go out
-// eight at a time: a single workgroup hides their latency only through loads in flight.
-__device__ __forceinline__ void gather_column_and_list(const double* __restrict__ M, int64_t ld, int64_t col, int64_t r_begin,
-                                                       int64_t r_end, double* __restrict__ colbuf, int32_t* __restrict__ idx,
-                                                       int* s_w, int32_t* __restrict__ count) {
-  int nz = 0;
-  for (int64_t rb = r_begin; rb < r_end; rb += 8) {
+// colbuf[r] = M[r * ld + col] for rows r = threadIdx.x, threadIdx.x + blockDim.x, ...; the strided
+// loads go out eight at a time: a single workgroup hides their latency only through loads in flight.
+__device__ __forceinline__ void gather_column(const double* __restrict__ M, int64_t ld, int64_t col, int64_t nrows,
+                                              double* __restrict__ colbuf) {
+  for (int64_t rb = threadIdx.x; rb < nrows; rb += 8 * (int64_t)blockDim.x) {
     double v[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = rb + q < r_end ? M[(rb + q) * ld + col] : 0.0;
+    for (int q = 0; q < 8; q++) {
+      const int64_t r = rb + q * (int64_t)blockDim.x;
+      v[q] = r < nrows ? M[r * ld + col] : 0.0;
+    }
 #pragma unroll
-    for (int q = 0; q < 8; q++)
-      if (rb + q < r_end) {
-        colbuf[rb + q] = v[q];
-        nz += v[q] != 0.0;
-      }
+    for (int q = 0; q < 8; q++) {
+      const int64_t r = rb + q * (int64_t)blockDim.x;
+      if (r < nrows) colbuf[r] = v[q];
+    }
   }
-  int total;
-  int at = block_exclusive_scan(nz, s_w, total);
-  for (int64_t r = r_begin; r < r_end; r++)
-    if (colbuf[r] != 0.0) idx[at++] = (int32_t)r;
-  if (threadIdx.x == 0) *count = total;
 }
 
 // kFirstNonZero == false: entering column = non-basic column (not the right-hand
@@ -252,18 +299,15 @@ __device__ __forceinline__ void gather_column_and_list(const double* __restrict_
 // kFirstNonZero == true: lowest non-basic column whose probe entry is non-zero, the
 //   column that replaces an artificial variable still basic after the feasibility
 //   phase (reference :148-163); none is ST_ERROR (the reference asserts).
-// With kGather the winner's column of Trm is then copied to colbuf, and the rows of its
-// non-zero entries are listed in ascending order in idx_col for the B^-1 * column
-// product; large problems leave that to k_rev_gather_wide + k_rev_list_nonzero, whose
-// strided loads (one page per row) are spread over the whole chip.
+// With kGather the winner's column of Trm is then copied to colbuf for the B^-1 * column
+// product; large problems leave that to k_rev_gather_wide, whose strided loads (one page
+// per row) are spread over the whole chip.
 template <bool kFirstNonZero, bool kGather>
 __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering(
     RevState* __restrict__ st, RevShape sh, int64_t ncols_active, const double* __restrict__ cost,
-    const uint8_t* __restrict__ is_basic, const double* __restrict__ Trm, double* __restrict__ colbuf,
-    int32_t* __restrict__ idx_col) {
+    const uint8_t* __restrict__ is_basic, const double* __restrict__ Trm, double* __restrict__ colbuf) {
   __shared__ double s_v[kRevSelectThreads / kWave];
   __shared__ int64_t s_i[kRevSelectThreads / kWave];
-  __shared__ int s_w[kRevSelectThreads / kWave + 1];
   __shared__ int64_t s_e;
   if (st->status != ST_RUNNING) return;
   const bool limit = !kFirstNonZero && st->iter >= st->max_iter;
@@ -301,10 +345,7 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering(
   __syncthreads();
   const int64_t e = s_e;
   if (!kGather || e < 0) return;
-  // every thread gathers a contiguous run of rows, which keeps the list ordered
-  const int64_t seg = (sh.m + kRevSelectThreads - 1) / kRevSelectThreads;
-  const int64_t r_begin = threadIdx.x * seg, r_end = r_begin + seg < sh.m ? r_begin + seg : sh.m;
-  gather_column_and_list(Trm, sh.ldw, e, r_begin, r_end, colbuf, idx_col, s_w, &st->n_col);
+  gather_column(Trm, sh.ldw, e, sh.m, colbuf);
 }
 
 // out[r] = M[r * ld + col] with one row per lane over the whole grid; col < 0 reads the
@@ -317,32 +358,25 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_gather_wide(
   if (r < nrows) out[r] = M[r * ld + col];
 }
 
-// Ascending list of the indices i < n with flag(i) set, where flag(i) is v[i] != 0 (v given) or
-// bytes[i] != 0; one workgroup, every thread a contiguous run, loads eight at a time.
-__device__ __forceinline__ void list_flagged(const double* __restrict__ v, const uint8_t* __restrict__ bytes, int64_t n,
-                                             int32_t* __restrict__ idx, int* s_w, int32_t* __restrict__ count) {
+// Ascending list of the indices i < n with bytes[i] != 0; one workgroup, every thread a
+// contiguous run, loads eight at a time.
+__device__ __forceinline__ void list_flagged(const uint8_t* __restrict__ bytes, int64_t n, int32_t* __restrict__ idx, int* s_w,
+                                             int32_t* __restrict__ count) {
   const int64_t seg = (n + kRevSelectThreads - 1) / kRevSelectThreads;
   const int64_t begin = threadIdx.x * seg, end = begin + seg < n ? begin + seg : n;
   int hits = 0;
   for (int64_t b = begin; b < end; b += 8) {
     bool f[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) f[q] = b + q < end && (v ? v[b + q] != 0.0 : bytes[b + q] != 0);
+    for (int q = 0; q < 8; q++) f[q] = b + q < end && bytes[b + q] != 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) hits += f[q];
   }
   int total;
   int at = block_exclusive_scan(hits, s_w, total);
   for (int64_t i = begin; i < end; i++)
-    if (v ? v[i] != 0.0 : bytes[i] != 0) idx[at++] = (int32_t)i;
+    if (bytes[i] != 0) idx[at++] = (int32_t)i;
   if (threadIdx.x == 0) *count = total;
-}
-
-__global__ __launch_bounds__(kRevSelectThreads) void k_rev_list_nonzero(
-    RevState* __restrict__ st, const double* __restrict__ v, int64_t n, int32_t* __restrict__ idx) {
-  __shared__ int s_w[kRevSelectThreads / kWave + 1];
-  if (st->status != ST_RUNNING) return;
-  list_flagged(v, nullptr, n, idx, s_w, &st->n_col);
 }
 
 // Ratio test over mu = B^-1 * column (reference :282-297) and everything of the
@@ -481,7 +515,7 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_finish_pivot(
   __shared__ int s_w[kRevSelectThreads / kWave + 1];
   if (st->status != ST_RUNNING) return;
   const int64_t e = st->e, it = st->iter, l = st->leaving;
-  list_flagged(nullptr, touched, sh.m, idx_upd, s_w, &st->n_upd);
+  list_flagged(touched, sh.m, idx_upd, s_w, &st->n_upd);
   if (threadIdx.x == 0) {
     mu[l] = 0.0;
     is_basic[e] = 1;

@@ -26,6 +26,34 @@ __global__ __launch_bounds__(256, 2) void k_rmw(Regions rg, int k, long chunks_p
   }
 }
 
+// read-only variant: every lane sums what it loads (one store per workgroup pass keeps the loads alive)
+__global__ __launch_bounds__(256, 2) void k_ro(Regions rg, int k, long chunks_per_region, double* sink) {
+  double acc = 0.0;
+  for (long c = blockIdx.x; c < k * chunks_per_region; c += gridDim.x) {
+    const double2* p = (const double2*)rg.base[c % k] + (c / k) * 4096 + threadIdx.x;
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { v[u].x = __builtin_nontemporal_load(&p[u * 256].x); v[u].y = __builtin_nontemporal_load(&p[u * 256].y); }
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc += v[u].x + v[u].y;
+  }
+  if (acc == 123.456) sink[0] = acc;
+}
+
+// out-of-place: read 64 KiB chunks from src, write them to dst
+__global__ __launch_bounds__(256, 2) void k_copy(const double2* __restrict__ src, double2* __restrict__ dst, long chunks, double f) {
+  for (long c = blockIdx.x; c < chunks; c += gridDim.x) {
+    const double2* p = src + c * 4096 + threadIdx.x;
+    double2* q = dst + c * 4096 + threadIdx.x;
+    double2 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { v[u].x = __builtin_nontemporal_load(&p[u * 256].x); v[u].y = __builtin_nontemporal_load(&p[u * 256].y); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < 16; u++) { __builtin_nontemporal_store(v[u].x * f + 1.0, &q[u * 256].x); __builtin_nontemporal_store(v[u].y * f + 1.0, &q[u * 256].y); }
+  }
+}
+
 int main(int argc, char** argv) {
   const double total_gb = 250.0;
   const size_t total = (size_t)(total_gb * 1e9);
@@ -57,6 +85,47 @@ int main(int argc, char** argv) {
     printf("%-44s %8.3f ms  %7.1f GB/s\n", label, ms / reps, bytes / (ms / reps * 1e-3) / 1e9);
     return 0;
   };
+  if (argc > 1 && std::string(argv[1]) == "copy") {   // 17.2 GB read from one place, written to another
+    const double pairs[][2] = {{0, 20}, {0, 40}, {0, 100}, {0, 150}, {100, 0}, {100, 120}, {150, 0}, {0, 215}};
+    for (auto& pr : pairs) {
+      const double2* src = (const double2*)(base + (((size_t)(pr[0] * 1e9) >> 21) << 21));
+      double2* dst = (double2*)(base + (((size_t)(pr[1] * 1e9) >> 21) << 21));
+      const long chunks = (long)(work / 65536);
+      for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, src, dst, chunks, 0.5);
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < 5; r++) hipLaunchKernelGGL(k_copy, dim3(8192), dim3(256), 0, 0, src, dst, chunks, 0.5);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("copy 17.2 GB from %5.0f GB to %5.0f GB  %8.3f ms  %7.1f GB/s (read + write)\n", pr[0], pr[1], ms / 5, 2.0 * work / (ms / 5 * 1e-3) / 1e9);
+    }
+    return 0;
+  }
+  if (argc > 1 && std::string(argv[1]) == "readonly") {   // read-only streams, 17.2 GB, one class vs two
+    auto run_ro = [&](const char* label, int k, const std::vector<double>& offs_gb) -> int {
+      Regions rg{};
+      const size_t region = (work / k) >> 16 << 16;
+      for (int i = 0; i < k; i++) rg.base[i] = base + (((size_t)(offs_gb[i] * 1e9) >> 21) << 21);
+      const long chunks = (long)(region / 65536);
+      for (int w = 0; w < 2; w++) hipLaunchKernelGGL(k_ro, dim3(8192), dim3(256), 0, 0, rg, k, chunks, (double*)base);
+      CK(hipEventRecord(e0));
+      for (int r = 0; r < 5; r++) hipLaunchKernelGGL(k_ro, dim3(8192), dim3(256), 0, 0, rg, k, chunks, (double*)base);
+      CK(hipEventRecord(e1));
+      CK(hipEventSynchronize(e1));
+      float ms = 0;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("read-only %-34s %8.3f ms  %7.1f GB/s\n", label, ms / 5, (double)region * k / (ms / 5 * 1e-3) / 1e9);
+      return 0;
+    };
+    run_ro("1 region at 0", 1, {0});
+    run_ro("1 region at 100", 1, {100});
+    run_ro("2 regions 0,36", 2, {0, 36});
+    run_ro("2 regions 0,100", 2, {0, 100});
+    run_ro("2 regions 0,150", 2, {0, 150});
+    run_ro("4 regions 0,80,150,215", 4, {0, 80, 150, 215});
+    return 0;
+  }
   if (argc > 1 && std::string(argv[1]) == "sweep") {   // two 2 GiB regions: one fixed, one swept over the allocation
     work = (size_t)4096 << 20;
     const double fixed = argc > 2 ? atof(argv[2]) : 0.0;

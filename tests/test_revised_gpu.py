@@ -72,8 +72,9 @@ def test_revised_synthetic_trace_and_inverse(lpamd, m, n, seed):
 
 
 @pytest.mark.parametrize("knobs", [{"LPAMD_REV_ROWDOT_ROWS": "64"}, {"LPAMD_REV_UPDATE_UNROLL": "16"},
-                                   {"LPAMD_REV_COLSUM_VEC": "2"}, {"LPAMD_REV_SPLIT": "1"},
-                                   {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_COLSUM_VEC": "2",
+                                   {"LPAMD_REV_TILE": "64"}, {"LPAMD_REV_TILE": "16"}, {"LPAMD_REV_TILE": "0"},
+                                   {"LPAMD_REV_TILE": "0", "LPAMD_REV_COLSUM_VEC": "2"}, {"LPAMD_REV_SPLIT": "1"},
+                                   {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_TILE": "64",
                                     "LPAMD_REV_SPLIT": "1"}])
 @pytest.mark.parametrize("m,n,seed", [(200, 333, 4), (65, 129, 5)])
 def test_revised_large_problem_kernel_shapes_on_small_lps(lpamd, monkeypatch, knobs, m, n, seed):
@@ -93,7 +94,7 @@ def test_revised_large_problem_kernel_shapes_on_small_lps(lpamd, monkeypatch, kn
 
 
 def test_revised_phase1_with_large_problem_kernel_shapes(lpamd, monkeypatch):
-    for k, v in {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_COLSUM_VEC": "2",
+    for k, v in {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_TILE": "64",
                  "LPAMD_REV_SPLIT": "1"}.items():
         monkeypatch.setenv(k, v)
     tab, rt = lo.revised_from_text(case_text("israel"))
@@ -106,8 +107,8 @@ def test_revised_phase1_with_large_problem_kernel_shapes(lpamd, monkeypatch):
 
 
 def test_revised_wide_tableau_and_many_rows(lpamd):
-    """Default kernel selection at sizes that switch variants: W >= 65536 (two columns per lane in
-    the pricing product) and m >= 16384 (64-row tiles, 16-deep update runs); first pivots only."""
+    """Default kernel selection at sizes that switch variants: wide tableau (64-wide tiles in the
+    pricing product) and m >= 16384 (64-row tiles, 16-deep update runs); first pivots only."""
     for m, n, seed, piv in [(64, 70000, 11, 12), (16384, 300, 12, 4)]:
         dt = lo.DenseTableau.synthetic(m, n, seed)
         rt = lo.RevisedTableau(dt.T, dt.obj, dt.is_basic, n + m, False)
