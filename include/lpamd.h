@@ -160,6 +160,22 @@ int lpamd_export_column_or_zero(lpamd_engine* eng, void* xbuf_dev);
  * lpamd_poll reports LPAMD_LIMIT both while running and when the budget is
  * spent; lpamd_pivot_count tells how far the loop got.  Synchronises. */
 int lpamd_set_pivot_budget(lpamd_engine* eng, int64_t max_pivots);
+/* Pieces of LPModel::TableauSimplexInitialize (reference lp_simplex_tableau.cc:64-171) for a
+ * caller that runs the feasibility phase over column shards (on one GPU lpamd_phase1 does it
+ * all).  The scans of that phase work on single rows, columns and the objective row, which
+ * the caller assembles from the shards with lpamd_read_row / lpamd_read_column /
+ * lpamd_download (each rank fills the entries of its own columns) and hands back with
+ * lpamd_write_objective.
+ * - lpamd_fill_column: sets every entry of a column (the artificial column: all ones at :82-86,
+ *   removed at :143); a no-op on ranks that do not own it.
+ * - lpamd_set_basic_flag: tableau_is_base_variable_[col] = flag (:71); no-op on non-owners.
+ * - lpamd_pivot_shard: LPModel::TableauPivot(base, non_base, r) (:10-52) on a shard: d = column
+ *   of `base` (< 0: none), e = column of `non_base`, ce = objective coefficient of e, xbuf_dev =
+ *   column e as exported by its owner (lpamd_export_column) and delivered to every rank (may be
+ *   NULL on the owner).  Synchronises. */
+int lpamd_fill_column(lpamd_engine* eng, int64_t col, double value);
+int lpamd_set_basic_flag(lpamd_engine* eng, int64_t col, int32_t flag);
+int lpamd_pivot_shard(lpamd_engine* eng, int64_t d, int64_t e, int64_t r, double ce, const void* xbuf_dev);
 /* terminal status after step 4 (synchronises): LPAMD_LIMIT = still running */
 int lpamd_poll(lpamd_engine* eng, int32_t* result);
 

@@ -750,6 +750,43 @@ int lpamd_pivot(lpamd_engine* e, int64_t d, int64_t col, int64_t r) {
   return pull_state(e);
 }
 
+int lpamd_pivot_shard(lpamd_engine* e, int64_t d, int64_t col, int64_t r, double ce, const void* xbuf_dev) {
+  CHECK_LOADED(e);
+  const Shape& sh = e->sh;
+  if (col < 0 || col > sh.N + 1 || col == sh.N || r < 0 || r >= sh.m || d > sh.N + 1)
+    return set_err(LPAMD_E_ARG, "pivot_shard: bad arguments d=%lld e=%lld r=%lld", (long long)d, (long long)col, (long long)r);
+  if (!xbuf_dev && !owns(e, col)) return set_err(LPAMD_E_ARG, "pivot_shard: column %lld lives on another rank and no exchange buffer was given", (long long)col);
+  LP_TRY(begin_step(e));
+  LP_TRY(ensure_trace(e, e->h_st.iter + 1));
+  const Candidate c{0.0, col, r, ce};
+  HIP_TRY(hipMemcpyAsync(e->cand, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));   // c is a stack object
+  LP_TRY(enqueue_pivot(e, false, e->cand, (const double*)xbuf_dev, d >= 0 ? d : (int64_t)(sh.N)));
+  return pull_state(e);
+}
+
+int lpamd_fill_column(lpamd_engine* e, int64_t col, double value) {
+  CHECK_LOADED(e);
+  if (col < 0 || col > e->sh.N + 1) return set_err(LPAMD_E_ARG, "fill_column: bad column %lld", (long long)col);
+  e->price_partials_fresh = false;
+  LP_TRY(invalidate_pr(e));
+  if (!owns(e, col)) return LPAMD_OK;
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((e->sh.m + 255) / 256)), dim3(256), 0, e->stream, e->T.col(local_of(e, col)), e->sh.m, value);
+  return check_launch("k_fill");
+}
+
+int lpamd_set_basic_flag(lpamd_engine* e, int64_t col, int32_t flag) {
+  CHECK_LOADED(e);
+  if (col < 0 || col > e->sh.N + 1 || col == e->sh.N) return set_err(LPAMD_E_ARG, "set_basic_flag: bad column %lld", (long long)col);
+  e->price_partials_fresh = false;
+  LP_TRY(invalidate_pr(e));
+  if (!owns(e, col)) return LPAMD_OK;
+  const uint8_t v = flag ? 1 : 0;
+  HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, col), &v, 1, hipMemcpyHostToDevice, e->stream));
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  return LPAMD_OK;
+}
+
 int lpamd_run_pivots(lpamd_engine* e, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
   CHECK_LOADED(e);
   LP_TRY(single_gpu_only(e, "lpamd_run_pivots"));

@@ -77,6 +77,9 @@ def library():
         "lpamd_set_pivot_budget": (ctypes.c_int, [vp, i64]),
         "lpamd_apply_pivot": (ctypes.c_int, [vp, i32, i64, i64, vp]),
         "lpamd_poll": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_fill_column": (ctypes.c_int, [vp, i64, ctypes.c_double]),
+        "lpamd_set_basic_flag": (ctypes.c_int, [vp, i64, i32]),
+        "lpamd_pivot_shard": (ctypes.c_int, [vp, i64, i64, i64, ctypes.c_double, vp]),
         "lpamd_rev_create": (ctypes.c_int, [P(vp), i64, i64, vp]),
         "lpamd_rev_destroy": (ctypes.c_int, [vp]),
         "lpamd_rev_upload": (ctypes.c_int, [vp, vp, i64, vp, vp, i32]),
@@ -275,6 +278,22 @@ class TableauEngine:
 
     def exchange_doubles(self):
         return int(self.L.lpamd_exchange_bytes(self.m)) // 8
+
+    # ---- pieces of the feasibility phase on shards ----
+    def owns(self, col):
+        """This rank holds global column `col` (the right-hand side is held everywhere)."""
+        if col == self.N:
+            return True
+        return (col if col < self.N else self.N) % self.world == self.rank
+
+    def fill_column(self, col, value):
+        _ck(self.L.lpamd_fill_column(self.h, int(col), float(value)))
+
+    def set_basic_flag(self, col, flag):
+        _ck(self.L.lpamd_set_basic_flag(self.h, int(col), 1 if flag else 0))
+
+    def pivot_shard(self, d, e, r, ce, xbuf_ptr):
+        _ck(self.L.lpamd_pivot_shard(self.h, int(d), int(e), int(r), float(ce), ctypes.c_void_p(xbuf_ptr) if xbuf_ptr else None))
 
 
 class RevisedTableauEngine:

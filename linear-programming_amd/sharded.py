@@ -15,10 +15,33 @@ bit-identical across ranks, so no further traffic is needed.
 `torch.distributed` carries both exchanges: backend "nccl" (RCCL over xGMI) on
 GPUs, "gloo" in the CPU tests, which plug in a host stand-in for the shard.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import engine as _eng
+
+_EPS32 = np.float32(1e-6)
+
+
+# reference base.h:61-66: the predicates narrow to float before comparing
+def _is_zero(x):
+    return abs(np.float32(x)) < _EPS32
+
+
+def _is_neg(x):
+    return np.float32(x) <= -_EPS32
+
+
+def _is_nonneg(x):
+    return np.float32(x) > -_EPS32
+
+
+def _flush(a):
+    """Zero drop of the tableau library after every add (reference lp_simplex_tableau.cc:5-8)."""
+    a = np.array(a, dtype=np.float64, copy=True)
+    a[np.abs(a) < float(_EPS32)] = 0.0
+    return a
 
 
 class EngineShard:
@@ -68,6 +91,63 @@ class EngineShard:
     def poll(self):
         return self.eng.poll()
 
+    # ---- pieces of the feasibility phase (host vectors are numpy, indexed by global column) ----
+    def owns(self, col):
+        return self.eng.owns(col)
+
+    def need_init(self):
+        return self.eng.need_init()
+
+    def read_row_local(self, i):
+        return self.eng.read_row(i)
+
+    def read_column(self, col):
+        return self.eng.read_column(col)
+
+    def download_objective(self):
+        return self.eng.download()[1]
+
+    def download_basic(self):
+        return self.eng.download()[2]
+
+    def write_objective(self, obj):
+        self.eng.write_objective(obj)
+
+    def fill_column(self, col, value):
+        self.eng.fill_column(col, value)
+
+    def set_basic_flag(self, col, flag):
+        self.eng.set_basic_flag(col, flag)
+
+    def pivot_shard(self, d, e, r, ce, xbuf):
+        self.eng.pivot_shard(d, e, r, ce, xbuf.data_ptr())
+
+    def objective_constant(self):
+        return self.eng.objective_constant()
+
+    def column_values(self):
+        return self.eng.column_values()
+
+
+class DistComm:
+    """The three exchanges of the sharded loop over torch.distributed (RCCL on GPUs, gloo on CPU).
+    Anything with the same five members can stand in for it (the tests use an in-process one)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+
+    def all_gather(self, out, inp):
+        dist.all_gather_into_tensor(out, inp, group=self.group)
+
+    def all_reduce_sum_words(self, words):
+        dist.all_reduce(words, op=dist.ReduceOp.SUM, group=self.group)
+
+    def broadcast(self, t, owner):
+        src = owner if self.group is None else dist.get_global_rank(self.group, owner)
+        dist.broadcast(t, src=src, group=self.group)
+
 
 class ShardedSolver:
     """Drives one shard per rank through the pivot loop.
@@ -81,15 +161,17 @@ class ShardedSolver:
     the owner and broadcasts the column from it.
     """
 
-    def __init__(self, shard, group=None, exchange="allreduce", poll_every=64):
+    def __init__(self, shard, group=None, exchange="allreduce", poll_every=64, comm=None):
         assert exchange in ("allreduce", "broadcast")
         self.shard = shard
-        self.group = group
+        if comm is None and dist.is_available() and dist.is_initialized():
+            comm = DistComm(group)               # collectives also run for a world of one
+        self.comm = comm
         self.exchange = exchange
         self.poll_every = poll_every
-        self.use_dist = dist.is_available() and dist.is_initialized()   # collectives also run for a world of one
-        self.rank = dist.get_rank(group) if self.use_dist else 0
-        self.world = dist.get_world_size(group) if self.use_dist else 1
+        self.use_dist = comm is not None
+        self.rank = comm.rank if comm is not None else 0
+        self.world = comm.world if comm is not None else 1
         assert self.world == shard.world and self.rank == shard.rank
         self.cand = shard.new_buffer(4)
         self.cands = shard.new_buffer(4 * self.world)
@@ -98,6 +180,7 @@ class ShardedSolver:
         if self.xbuf.is_cuda:
             # the zero-fills above ran on the allocating stream; the loop uses the shard's own stream
             torch.cuda.synchronize(self.xbuf.device)
+        self.wbuf = None    # N + 2 doubles, created by the first solve()
 
     def run_pivots(self, strategy, k):
         """At most k pivots (k < 0: until termination).  Returns (Result, pivots done)."""
@@ -110,7 +193,7 @@ class ShardedSolver:
 
     def _gather_candidates(self):
         if self.use_dist:
-            dist.all_gather_into_tensor(self.cands, self.cand, group=self.group)
+            self.comm.all_gather(self.cands, self.cand)
         else:
             self.cands.copy_(self.cand)
 
@@ -127,7 +210,7 @@ class ShardedSolver:
                 sh.select_candidate_device(strategy, self.cands)
                 sh.export_column_or_zero(self.xbuf)
                 if self.use_dist:
-                    dist.all_reduce(self.xbuf_words, op=dist.ReduceOp.SUM, group=self.group)
+                    self.comm.all_reduce_sum_words(self.xbuf_words)
                 sh.apply_pivot(strategy, -1, -1, self.xbuf)
             enqueued += n
             res = sh.poll()                  # the only host synchronisation
@@ -148,9 +231,168 @@ class ShardedSolver:
             if owner == self.rank:
                 sh.export_column(e, self.xbuf)
             if self.use_dist:
-                src = owner if self.group is None else dist.get_global_rank(self.group, owner)
-                dist.broadcast(self.xbuf, src=src, group=self.group)
+                self.comm.broadcast(self.xbuf, owner)
             sh.apply_pivot(strategy, e, r, self.xbuf)
             done += 1
         res = sh.poll()
         return res, done
+
+    # ---- TableauSimplexSolve on shards: feasibility phase included ------------------------
+    # The scans of reference lp_simplex_tableau.cc:64-171 look at single rows, columns and
+    # the objective row.  Every rank assembles them from the shards with an exact sum
+    # (only the owner of an entry contributes a non-zero bit pattern), takes the same
+    # decisions on the same data, and applies the same explicit pivots to its shard.
+
+    def _sum_exact(self, vec, buf):
+        """All ranks get the element-wise 64-bit integer sum of `vec` (float64 numpy)."""
+        n = len(vec)
+        t = buf[:n]
+        t.copy_(torch.from_numpy(np.ascontiguousarray(vec, dtype=np.float64)))
+        if self.use_dist:
+            self.comm.all_reduce_sum_words(t.view(torch.int64))
+        return t.cpu().numpy().copy()
+
+    def _assemble(self, local_vec):
+        """Full N+2 vector from per-rank vectors that hold the local columns only; the
+        replicated right-hand-side entry is taken from rank 0."""
+        v = np.array(local_vec, dtype=np.float64, copy=True)
+        if self.rank != 0:
+            v[self.shard.N] = 0.0
+        return self._sum_exact(v, self.wbuf)
+
+    def _column(self, col):
+        """Column `col` on every rank (read by its owner)."""
+        m = self.shard.m
+        v = np.zeros(m, dtype=np.float64)
+        if col == self.shard.N:
+            return self.shard.read_column(col)
+        if self.shard.owns(col):
+            v = self.shard.read_column(col)
+        return self._sum_exact(v, self.xbuf)
+
+    def _pivot(self, d, e, r, ce):
+        """LPModel::TableauPivot(d -> out, e -> in, row r) on every shard."""
+        sh = self.shard
+        if self.use_dist or not sh.owns(e):
+            self.xbuf.zero_()
+            if sh.owns(e):
+                sh.export_column(e, self.xbuf)
+            if self.use_dist:
+                self.comm.all_reduce_sum_words(self.xbuf_words)
+        else:
+            sh.export_column(e, self.xbuf)
+        sh.pivot_shard(d, e, r, ce, self.xbuf)
+
+    def _phase1(self, strategy):
+        sh = self.shard
+        N, A, W, m = sh.N, sh.N + 1, sh.N + 2, sh.m
+        if not sh.need_init():
+            return _eng.SOLVED
+        saved = self._assemble(sh.download_objective())
+        tmp = np.zeros(W, dtype=np.float64)
+        tmp[A] = -1.0                                                    # :79
+        sh.write_objective(tmp)
+        sh.set_basic_flag(A, 0)                                          # :71
+        sh.fill_column(A, 1.0)                                           # :82-86
+        rhs = sh.read_column(N)
+        r, mv = -1, 0.0
+        for i in range(m):                                               # MinReduce, ties to the later row (:88-91)
+            if not (mv < rhs[i]):
+                mv, r = rhs[i], i
+        if r < 0:
+            return _eng.ERROR
+        row = self._assemble(sh.read_row_local(r))
+        basic = self._assemble(sh.download_basic().astype(np.float64)) != 0.0
+        d = -1
+        for j in range(W):                                               # :94-104
+            if j == N or _is_zero(row[j]):
+                continue
+            if basic[j]:
+                d = j
+                break
+        if d < 0:
+            return _eng.ERROR
+        self._pivot(d, A, r, tmp[A])
+        rhs = sh.read_column(N)
+        if any(not _is_nonneg(b) for b in rhs):                          # :106-108 (live assert upstream)
+            return _eng.ERROR
+        inner, _ = self.run_pivots(strategy, -1)                         # :110
+        if inner != _eng.SOLVED:
+            return _eng.ERROR                                            # :111 (live assert upstream)
+        if _is_neg(sh.objective_constant()):
+            return _eng.NOSOLUTION                                       # :113-115
+        basic = self._assemble(sh.download_basic().astype(np.float64)) != 0.0
+        if basic[A]:                                                     # :117-135
+            col_a = self._column(A)
+            pivoted = False
+            for i in range(m):
+                if pivoted:
+                    break
+                if _is_zero(col_a[i]):
+                    continue
+                row = self._assemble(sh.read_row_local(i))
+                for j in range(W):
+                    if j != N and basic[j]:
+                        continue
+                    if _is_zero(row[j]):
+                        continue
+                    if j == N:
+                        return _eng.ERROR   # upstream would pivot on the constant column and abort on its assert
+                    obj_now = self._assemble(sh.download_objective())
+                    self._pivot(A, j, i, obj_now[j])
+                    pivoted = True
+                    break
+            if not pivoted:
+                return _eng.ERROR
+            sh.set_basic_flag(A, 0)
+            basic = self._assemble(sh.download_basic().astype(np.float64)) != 0.0
+        sh.fill_column(A, 0.0)                                           # :143
+        saved[A] = 0.0
+        acc = np.zeros(W, dtype=np.float64)                              # objective re-expression (:149-166)
+        for j in range(W):
+            if j == N or not basic[j] or _is_zero(saved[j]):
+                continue
+            col = self._column(j)
+            rho, bv = -1, float(_EPS32)                                  # MaxAbsReduce init {-1, kEpsilonF}
+            for i in range(m):
+                if not (abs(bv) > abs(col[i])):
+                    bv, rho = col[i], i
+            if rho < 0:
+                return _eng.ERROR
+            row = self._assemble(sh.read_row_local(rho))
+            s = -saved[j] / row[j]                                       # :162
+            acc = _flush(acc + row * s)
+        saved = _flush(saved + acc)                                      # :166
+        sh.write_objective(saved)
+        return _eng.SOLVED
+
+    def solve(self, strategy, max_pivots=-1):
+        """LPModel::TableauSimplexSolve (reference lp_simplex_tableau.cc:173-379) over the
+        shards: feasibility phase if the right-hand side needs it, then the pivot loop
+        (max_pivots limits the loop after that phase).  Returns (Result, pivots applied)."""
+        if strategy not in (_eng.MAX_COST, _eng.MAX_REDUCTION):
+            raise _eng.LpamdError("pivoting strategy %r is not implemented for the tableau path" % (strategy,))
+        sh = self.shard
+        if self.wbuf is None:
+            self.wbuf = sh.new_buffer(sh.N + 2)
+            if self.wbuf.is_cuda:
+                torch.cuda.synchronize(self.wbuf.device)
+        start = sh.pivot_count()
+        stream = getattr(sh, "stream", None)
+        if sh.need_init():
+            if stream is None:
+                r1 = self._phase1(strategy)
+            else:
+                with torch.cuda.stream(stream):
+                    r1 = self._phase1(strategy)
+            if r1 != _eng.SOLVED:
+                return (_eng.NOSOLUTION if r1 == _eng.NOSOLUTION else _eng.ERROR), sh.pivot_count() - start
+            if sh.need_init():
+                return _eng.ERROR, sh.pivot_count() - start              # :179
+        res, _ = self.run_pivots(strategy, max_pivots)
+        return res, sh.pivot_count() - start
+
+    def column_values(self):
+        """x[j] of every global column on every rank (GetTableauSimplexSolution's values)."""
+        x = self.shard.column_values()
+        return self._assemble(x)

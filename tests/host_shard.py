@@ -120,6 +120,7 @@ class HostShard:
 
     def set_pivot_budget(self, k):
         self.budget_end = None if k < 0 else len(self.trace) + k
+        self.status = eng.LIMIT                 # re-arms a loop that has terminated (the engine does the same)
 
     def pivot_count(self):
         return len(self.trace)
@@ -142,11 +143,12 @@ class HostShard:
                 return
             ratios = self.rhs[rows] / (-col[rows])
             r = int(rows[int(np.argmin(ratios))])
+        self._pivot(int(self.basis[r]), e, r, float(self.winner[3]), col)
+
+    def _pivot(self, d, e, r, ce, col):
         a = col[r]
-        ce = float(self.winner[3])
         f = -1.0 / a
         g = ce * f
-        d = int(self.basis[r])
         rowp = self.T[r, :] * f
         rhs_rowp = self.rhs[r] * f
         self.obj = flush(self.obj + self.T[r, :] * g)
@@ -163,6 +165,66 @@ class HostShard:
                 self.basic[l] = 0
         self.basis[r] = e
         self.trace.append((int(e), int(r)))
+
+    # ---- pieces of the feasibility phase ----
+    def owns(self, col):
+        return col == self.N or bool(np.any(self.gcols == col))
+
+    def _local(self, col):
+        return int(np.nonzero(self.gcols == col)[0][0])
+
+    def need_init(self):
+        return bool(np.any(f32(self.rhs) <= np.float32(-1e-6)))
+
+    def read_row_local(self, i):
+        out = np.zeros(self.N + 2, dtype=np.float64)
+        out[self.gcols] = self.T[i, :]
+        out[self.N] = self.rhs[i]
+        return out
+
+    def read_column(self, col):
+        return self.rhs.copy() if col == self.N else np.array(self.T[:, self._local(col)], dtype=np.float64)
+
+    def download_objective(self):
+        out = np.zeros(self.N + 2, dtype=np.float64)
+        out[self.gcols] = self.obj
+        out[self.N] = self.obj_const
+        return out
+
+    def download_basic(self):
+        out = np.zeros(self.N + 2, dtype=np.uint8)
+        out[self.gcols] = self.basic
+        return out
+
+    def write_objective(self, obj):
+        self.obj = np.array(obj[self.gcols], dtype=np.float64)
+        self.obj_const = float(obj[self.N])
+
+    def fill_column(self, col, value):
+        if col != self.N and self.owns(col):
+            self.T[:, self._local(col)] = value
+
+    def set_basic_flag(self, col, flag):
+        if col != self.N and self.owns(col):
+            self.basic[self._local(col)] = 1 if flag else 0
+
+    def pivot_shard(self, d, e, r, ce, xbuf):
+        self.status = eng.LIMIT
+        self._pivot(d, e, r, ce, np.array(xbuf.numpy()[: self.m], dtype=np.float64))
+
+    def objective_constant(self):
+        return self.obj_const
+
+    def column_values(self):
+        x = np.zeros(self.N + 2, dtype=np.float64)
+        for l, gc in enumerate(self.gcols):
+            if not self.basic[l]:
+                continue
+            nz = np.nonzero(np.abs(f32(self.T[:, l])) >= np.float32(1e-6))[0]
+            if len(nz):
+                i = int(nz[-1])                   # last such row wins
+                x[gc] = -self.rhs[i] / self.T[i, l]
+        return x
 
     def poll(self):
         return self.status

@@ -74,3 +74,44 @@ def test_two_rank_loop_matches_oracle(tmp_path, case, strategy, exchange):
     assert np.array_equal(ranks[0]["rhs"].view(np.uint64), ranks[1]["rhs"].view(np.uint64))
     assert np.array_equal(T.view(np.uint64), dt.T.view(np.uint64))
     assert np.array_equal(obj.view(np.uint64), dt.obj.view(np.uint64))
+
+
+def _solve_worker(rank, world, port, name, strategy_name, out_dir, exchange):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from host_shard import HostShard
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    tab, _ = lo.from_text(case_text(name))
+    shard = HostShard(tab.T, tab.obj, tab.is_basic, tab.N, rank, world)
+    solver = sharded.ShardedSolver(shard, exchange=exchange, poll_every=5)
+    res, done = solver.solve(eng.STRATEGY[strategy_name])
+    x = solver.column_values()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), res=res, done=done, trace=np.array(shard.trace, dtype=np.int64).reshape(-1, 2),
+             x=x, obj_const=shard.obj_const, rhs=shard.rhs)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,strategy,exchange,world", [
+    ("test15", "max_cost", "allreduce", 2), ("test16", "max_reduction", "broadcast", 2),
+    ("afiro", "max_cost", "allreduce", 3), ("test17", "max_reduction", "allreduce", 2),
+])
+def test_sharded_solve_with_feasibility_phase_matches_oracle_and_golden(tmp_path, name, strategy, exchange, world):
+    """TableauSimplexSolve over shards, feasibility phase included: every rank walks the oracle's
+    pivots (phase 1 and artificial pivot-out included) and the printed solution is the reference's golden."""
+    from cases import case_golden
+    from oracle import lp_frontend as fe
+    mp.spawn(_solve_worker, args=(world, _free_port(), name, strategy, str(tmp_path), exchange), nprocs=world, join=True)
+    tab, dt = lo.from_text(case_text(name))
+    assert dt.need_init()
+    want = dt.solve(lo.STRATEGY[strategy])
+    ranks = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    for r in ranks:
+        assert int(r["res"]) == want == lo.SOLVED
+        assert [tuple(x) for x in r["trace"].tolist()] == dt.trace()
+        assert int(r["done"]) == dt.n_pivots
+        assert np.array_equal(r["rhs"].view(np.uint64), ranks[0]["rhs"].view(np.uint64))
+        assert np.array_equal(r["x"].view(np.uint64), dt.column_values().view(np.uint64))
+        out = fe.format_solution(tab, r["x"], float(r["obj_const"]))
+        assert out.rstrip("\n") == case_golden(name, strategy).rstrip("\n")

@@ -199,3 +199,125 @@ def test_rccl_collectives_single_rank(lpamd, exchange):
     finally:
         dist.destroy_process_group()
 
+
+class ThreadComm:
+    """In-process stand-in for sharded.DistComm: one solver thread per rank, all on this GPU.
+    Every exchange is two barriers around a read of the other ranks' tensors."""
+
+    def __init__(self, shared, rank, world):
+        self.shared, self.rank, self.world = shared, rank, world
+
+    def _sync(self):
+        torch.cuda.synchronize()
+        self.shared["barrier"].wait(timeout=100)
+
+    def _exchange(self, mine, combine):
+        self.shared["slots"][self.rank] = mine
+        self._sync()
+        out = combine([self.shared["slots"][r] for r in range(self.world)])
+        self._sync()                       # everybody has read before anybody overwrites
+        return out
+
+    def all_gather(self, out, inp):
+        out.copy_(self._exchange(inp, lambda parts: torch.cat(parts)))
+
+    def all_reduce_sum_words(self, words):
+        words.copy_(self._exchange(words, lambda parts: torch.stack(parts).sum(dim=0)))
+
+    def broadcast(self, t, owner):
+        t.copy_(self._exchange(t, lambda parts: parts[owner].clone()))
+
+
+def solve_in_threads(lpamd, tab, world, strategy, exchange):
+    import threading
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    shared = {"barrier": threading.Barrier(world), "slots": [None] * world}
+    out, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            shard = sharded.EngineShard(tab.m, tab.N, rank, world, dev)
+            shard.eng.upload(tab.T, tab.obj, tab.is_basic)
+            solver = sharded.ShardedSolver(shard, exchange=exchange, poll_every=6, comm=ThreadComm(shared, rank, world))
+            res, done = solver.solve(eng.STRATEGY[strategy])
+            x = solver.column_values()
+            torch.cuda.synchronize()
+            out[rank] = (res, done, shard.eng.trace(), x, shard.eng.objective_constant(), shard.eng.read_column(tab.N))
+            shard.eng.close()
+        except BaseException as ex:   # noqa: B036 - reported by the caller
+            errors.append((rank, repr(ex)))
+            shared["barrier"].abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=150)
+    assert not errors, errors
+    assert all(o is not None for o in out)
+    return out
+
+
+@pytest.mark.parametrize("name,strategy,exchange,world", [
+    ("test15", "max_cost", "allreduce", 2), ("test16", "max_reduction", "allreduce", 3),
+    ("afiro", "max_cost", "broadcast", 2), ("kb2", "max_reduction", "allreduce", 2),
+    ("adlittle", "max_cost", "allreduce", 4),
+])
+def test_sharded_solve_with_feasibility_phase_on_gpu(lpamd, name, strategy, exchange, world):
+    """TableauSimplexSolve over real engine shards (one solver thread per rank on this GPU, in-process
+    exchange): feasibility phase, artificial pivot-out and objective re-expression included; every
+    rank walks the oracle's pivots and the solution prints as the reference's golden."""
+    from cases import case_golden
+    from oracle import lp_frontend as fe
+    tab, dt = lo.from_text(case_text(name))
+    assert dt.need_init() or name == "kb2"    # kb2 starts feasible: the same driver without the phase
+    want = dt.solve(lo.STRATEGY[strategy])
+    ranks = solve_in_threads(lpamd, tab, world, strategy, exchange)
+    for res, done, trace, x, oc, rhs in ranks:
+        assert res == want == lpamd.SOLVED
+        assert trace == dt.trace() and done == dt.n_pivots
+        assert np.array_equal(bits(rhs), bits(ranks[0][5]))
+        assert np.array_equal(bits(x), bits(dt.column_values()))
+        assert fe.format_solution(tab, x, oc).rstrip("\n") == case_golden(name, strategy).rstrip("\n")
+
+
+def test_sharded_solve_reports_infeasible_and_unbounded(lpamd):
+    for text, want in (("max x1\nst\nx1 <= 1\nx1 >= 2\nx1 >= 0\n", lo.NOSOLUTION),
+                       ("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n", lo.UNBOUNDED)):
+        tab, dt = lo.from_text(text)
+        assert dt.solve(lo.MAX_COST) == want
+        for res, done, trace, x, oc, rhs in solve_in_threads(lpamd, tab, 2, "max_cost", "allreduce"):
+            assert res == want and trace == dt.trace()
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "broadcast"])
+def test_rccl_single_rank_solve_with_feasibility_phase(lpamd, exchange):
+    """The same solve over the nccl (= RCCL) backend with a world of one."""
+    import socket
+    import torch.distributed as dist
+    from cases import case_golden
+    from oracle import lp_frontend as fe
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    try:
+        tab, dt = lo.from_text(case_text("israel"))
+        want = dt.solve(lo.MAX_COST)
+        shard = sharded.EngineShard(tab.m, tab.N, 0, 1, dev)
+        shard.eng.upload(tab.T, tab.obj, tab.is_basic)
+        solver = sharded.ShardedSolver(shard, exchange=exchange, poll_every=16)
+        res, done = solver.solve(eng.MAX_COST)
+        assert res == want == eng.SOLVED and shard.eng.trace() == dt.trace()
+        x = solver.column_values()
+        assert fe.format_solution(tab, x, shard.eng.objective_constant()).rstrip("\n") == case_golden("israel", "max_cost").rstrip("\n")
+    finally:
+        dist.destroy_process_group()
