@@ -187,10 +187,13 @@ int rev_enqueue_update(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
   const int grid = 4096;   // work items (listed row x run of vectors) are dealt round-robin
   const bool unroll16 = h->force_update_unroll ? h->force_update_unroll == 16 : sh.ldb >= 8192;
-  if (unroll16)
-    hipLaunchKernelGGL((k_rev_update<16>), dim3(grid), dim3(kRevThreads), 0, h->stream, h->st, sh, h->BinvT, h->mu, h->scaled, h->idx_upd);
-  else
-    hipLaunchKernelGGL((k_rev_update<4>), dim3(grid), dim3(kRevThreads), 0, h->stream, h->st, sh, h->BinvT, h->mu, h->scaled, h->idx_upd);
+  // nt loads/stores once the inverse exceeds the Infinity Cache, as in the tableau update
+  const bool nt = (double)sh.m * (double)sh.ldb * sizeof(double) > 512e6;
+#define LPAMD_REV_UPDATE(U, NT) \
+  hipLaunchKernelGGL((k_rev_update<U, NT>), dim3(grid), dim3(kRevThreads), 0, h->stream, h->st, sh, h->BinvT, h->mu, h->scaled, h->idx_upd)
+  if (unroll16) { if (nt) LPAMD_REV_UPDATE(16, true); else LPAMD_REV_UPDATE(16, false); }
+  else { if (nt) LPAMD_REV_UPDATE(4, true); else LPAMD_REV_UPDATE(4, false); }
+#undef LPAMD_REV_UPDATE
   return check_launch("k_rev_update");
 }
 

@@ -537,7 +537,7 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_finish_pivot(
 // (every stored entry is already a fixed point of the zero drop after the first,
 // full, update).  A work item is one run of kUnroll * 256 16-byte vectors of one
 // row; all loads of a run are issued before its first store.
-template <int kUnroll>
+template <int kUnroll, bool kNT>
 __global__ __launch_bounds__(kRevThreads, 2) void k_rev_update(
     const RevState* __restrict__ st, RevShape sh, double* __restrict__ BinvT, const double* __restrict__ mu,
     const double* __restrict__ scaled, const int32_t* __restrict__ idx_upd) {
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(kRevThreads, 2) void k_rev_update(
 #pragma unroll
     for (int q = 0; q < kUnroll; q++) {
       const int v = v0 + q * kRevThreads;
-      if (v < n_vec) { x[q] = p[v]; c[q] = mu2[v]; }
+      if (v < n_vec) { x[q] = ld16<kNT>(p + v); c[q] = mu2[v]; }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(kRevThreads, 2) void k_rev_update(
         if (2 * (int64_t)v + 1 == l) x[q].y = u;
         x[q].x = flushz(__dadd_rn(x[q].x, __dmul_rn(c[q].x, u)));
         x[q].y = flushz(__dadd_rn(x[q].y, __dmul_rn(c[q].y, u)));
-        p[v] = x[q];
+        st16<kNT>(p + v, x[q]);
       }
     }
   }

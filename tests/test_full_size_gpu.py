@@ -1,4 +1,4 @@
-"""GPU, BASELINE sizes.  m=4096 n=8192 is still cheap enough for the oracle, so the
+"""GPU, the sizes of the headline benchmark.  m=4096 n=8192 is still cheap enough for the oracle, so the
 first pivots are compared bit for bit; m=32768 n=65536 (25.8 GB on the device)
 is checked through size-independent properties of the simplex tableau."""
 import numpy as np
