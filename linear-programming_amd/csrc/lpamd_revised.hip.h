@@ -25,6 +25,10 @@ struct lpamd_rev_engine {
   double* colbuf = nullptr;
   double* scaled = nullptr;
   int32_t* idx_upd = nullptr;   // rows of BinvT the pending update visits
+  int32_t* idx_rows = nullptr;  // rows of the tableau with a non-zero entry of p (pricing product)
+  int32_t* idx_dense = nullptr; // rows of BinvT that an update has touched (ascending)
+  uint8_t* dense = nullptr;     // the same as a byte per row
+  int64_t* pos = nullptr;       // row of BinvT -> position of its single start entry (-1: none)
   uint8_t* touched = nullptr;   // one byte per row of BinvT: the pending update visits it
   RevState* st = nullptr;
   int64_t* trace = nullptr;
@@ -42,7 +46,11 @@ struct lpamd_rev_engine {
   // LPAMD_REV_SPLIT=0|1: strided gathers inside the single-workgroup selection kernels / as
   // chip-wide kernels of their own (default: by size)
   // LPAMD_REV_TILE=0|16|64: column products one lane per output / through LDS tiles 16 or 64 outputs wide
+  // LPAMD_REV_LIST=0: no row list in the pricing product (64-row chunk skipping only)
   int force_vec = 0, force_rowdot_rows = 0, force_update_unroll = 0, force_split = -1, force_tile = -1;
+  bool list_rows = true;
+  // LPAMD_REV_UNIT=0: the products over the inverse read every row instead of the dense rows only
+  bool unit_rows = true;
   bool split() const { return force_split >= 0 ? force_split != 0 : sh.m > 8192; }
 };
 
@@ -56,13 +64,15 @@ namespace {
 
 void rev_free(lpamd_rev_engine* h) {
   void* ptrs[] = {h->Trm, h->BinvT, h->obj, h->cost, h->is_basic, h->negate, h->basis, h->rows, h->xB,
-                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_upd, h->touched, h->st, h->trace};
+                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_upd, h->idx_rows, h->idx_dense, h->dense, h->pos, h->touched, h->st, h->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->Trm = h->BinvT = h->obj = h->cost = h->xB = h->cB = h->pvec = h->mu = h->colbuf = h->scaled = nullptr;
   h->is_basic = h->negate = h->touched = nullptr;
   h->basis = h->rows = h->trace = nullptr;
-  h->idx_upd = nullptr;
+  h->idx_upd = h->idx_rows = h->idx_dense = nullptr;
+  h->dense = nullptr;
+  h->pos = nullptr;
   h->st = nullptr;
   h->trace_cap = 0;
 }
@@ -87,6 +97,10 @@ int rev_allocate(lpamd_rev_engine* h, int64_t W) {
   HIP_TRY(hipMalloc(&h->basis, sizeof(int64_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->rows, sizeof(int64_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->idx_upd, sizeof(int32_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->idx_rows, sizeof(int32_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->idx_dense, sizeof(int32_t) * sh.ldb));
+  HIP_TRY(hipMalloc(&h->dense, sh.ldb));
+  HIP_TRY(hipMalloc(&h->pos, sizeof(int64_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->touched, sh.ldb));
   double** vecs[] = {&h->xB, &h->cB, &h->pvec, &h->mu, &h->colbuf, &h->scaled};
   for (double** v : vecs) {
@@ -140,18 +154,46 @@ int rev_upload_obj(lpamd_rev_engine* h) {
 }
 
 // out[0..ncols) = sum over rows of coef[r] * M[r][.] (+ base with the zero drop when it is given)
+// list_rows: first list the rows with a non-zero coefficient and read only those (pays when the
+// non-zeros are few and scattered, as those of p are for thousands of pivots).
+// over_inverse: M is the transposed inverse; only its dense rows are read and every output takes
+// the single term of its unit row (k_rev_coltile<.., kUnit>).
 int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, int64_t ncols, const double* coef,
-               const double* base, double* out) {
+               const double* base, double* out, bool list_rows = false, bool over_inverse = false) {
   // LDS-tiled product: 64 outputs per workgroup once that fills the chip, 16 below.  Measured at
   // m=32768 n=65536 with a dense coefficient vector: 2.87 / 1.18 ms against 3.58 / 1.49 ms for one
   // lane per output (pricing / B^-1 column); at m=4096: 0.30 against 0.47 ms per pivot.
   const int tile = h->force_tile >= 0 ? h->force_tile : (ncols >= 64 * 256 ? 64 : 16);
   if (tile == 64 || tile == 16) {
     const dim3 tgrid((unsigned)((ncols + tile - 1) / tile)), tblock(kRevThreads);
-#define LPAMD_REV_COLTILE(W, C) \
-  hipLaunchKernelGGL((k_rev_coltile<W, C>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out)
-    if (tile == 64) { if (base) LPAMD_REV_COLTILE(64, true); else LPAMD_REV_COLTILE(64, false); }
-    else { if (base) LPAMD_REV_COLTILE(16, true); else LPAMD_REV_COLTILE(16, false); }
+    if (over_inverse && h->unit_rows && !base) {
+      const int32_t* n_dense = &h->st->n_dense;
+      if (tile == 64)
+        hipLaunchKernelGGL((k_rev_coltile<64, false, true, true>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out,
+                           h->idx_dense, n_dense, h->rows, h->dense);
+      else
+        hipLaunchKernelGGL((k_rev_coltile<16, false, true, true>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out,
+                           h->idx_dense, n_dense, h->rows, h->dense);
+      return check_launch("k_rev_coltile");
+    }
+    const int32_t* rows = nullptr;
+    const int32_t* n_listed = nullptr;
+    if (list_rows && h->list_rows) {
+      hipLaunchKernelGGL(k_rev_list_nonzero, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, coef, nrows, h->idx_rows, &h->st->n_rows);
+      LP_TRY(check_launch("k_rev_list_nonzero"));
+      rows = h->idx_rows;
+      n_listed = &h->st->n_rows;
+    }
+#define LPAMD_REV_COLTILE(W, C, L) \
+  hipLaunchKernelGGL((k_rev_coltile<W, C, L>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out, rows, n_listed)
+#define LPAMD_REV_COLTILE_L(W, C)                         \
+  do {                                                    \
+    if (rows) LPAMD_REV_COLTILE(W, C, true);              \
+    else LPAMD_REV_COLTILE(W, C, false);                  \
+  } while (0)
+    if (tile == 64) { if (base) LPAMD_REV_COLTILE_L(64, true); else LPAMD_REV_COLTILE_L(64, false); }
+    else { if (base) LPAMD_REV_COLTILE_L(16, true); else LPAMD_REV_COLTILE_L(16, false); }
+#undef LPAMD_REV_COLTILE_L
 #undef LPAMD_REV_COLTILE
     return check_launch("k_rev_coltile");
   }
@@ -173,14 +215,25 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
 int rev_rowdot(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
   // 64 rows per workgroup need m / 64 >= 256 workgroups to fill the chip; below that 16 rows
+  // (16-row tiles for a short dense-row list were tried and lost: the 256-step chains per chunk cost
+  // more than the shorter load waits gain, 0.42 against 0.36 ms per pivot.)
   const bool rows64 = h->force_rowdot_rows ? h->force_rowdot_rows == 64 : sh.m >= 16384;
-  if (rows64)
-    hipLaunchKernelGGL((k_rev_rowdot<64>), dim3((unsigned)((sh.m + 63) / 64)), dim3(kRevThreads), 0, h->stream, h->st, h->BinvT, sh.ldb,
-                       sh.m, sh.m, h->cB, h->pvec);
-  else
-    hipLaunchKernelGGL((k_rev_rowdot<16>), dim3((unsigned)((sh.m + 15) / 16)), dim3(kRevThreads), 0, h->stream, h->st, h->BinvT, sh.ldb,
-                       sh.m, sh.m, h->cB, h->pvec);
-  return check_launch("k_rev_rowdot");
+  const int kr = rows64 ? 64 : 16;
+  const dim3 grid((unsigned)((sh.m + kr - 1) / kr)), block(kRevThreads);
+  const int32_t* rows = h->unit_rows ? h->idx_dense : nullptr;
+  const int32_t* n_listed = h->unit_rows ? &h->st->n_dense : nullptr;
+#define LPAMD_REV_ROWDOT(R, L) \
+  hipLaunchKernelGGL((k_rev_rowdot<R, L>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed)
+  if (rows64) { if (rows) LPAMD_REV_ROWDOT(64, true); else LPAMD_REV_ROWDOT(64, false); }
+  else { if (rows) LPAMD_REV_ROWDOT(16, true); else LPAMD_REV_ROWDOT(16, false); }
+#undef LPAMD_REV_ROWDOT
+  LP_TRY(check_launch("k_rev_rowdot"));
+  if (rows) {
+    hipLaunchKernelGGL(k_rev_unit_rows_p, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
+                       h->BinvT, sh.ldb, sh.m, h->cB, h->pos, h->dense, h->pvec);
+    LP_TRY(check_launch("k_rev_unit_rows_p"));
+  }
+  return LPAMD_OK;
 }
 
 int rev_enqueue_update(lpamd_rev_engine* h) {
@@ -220,20 +273,20 @@ int rev_enqueue_entering(lpamd_rev_engine* h, bool first_nonzero, int64_t ncols_
 int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
   const RevShape& sh = h->sh;
   const dim3 one(1), sel(kRevSelectThreads);
-  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, sh.m, h->colbuf, nullptr, h->mu));
+  LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, sh.m, h->colbuf, nullptr, h->mu, false, true));
   if (!h->split()) {
     hipLaunchKernelGGL((k_rev_select_leaving<true>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
-                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap);
+                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
     LP_TRY(check_launch("k_rev_select_leaving"));
   } else {
     hipLaunchKernelGGL((k_rev_select_leaving<false>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
-                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap);
+                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
     LP_TRY(check_launch("k_rev_select_leaving"));
     hipLaunchKernelGGL(k_rev_pivot_vectors, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
-                       h->st, sh, h->mu, h->xB, h->BinvT, h->scaled, h->touched);
+                       h->st, sh, h->mu, h->xB, h->BinvT, h->scaled, h->touched, h->dense);
     LP_TRY(check_launch("k_rev_pivot_vectors"));
     hipLaunchKernelGGL(k_rev_finish_pivot, one, sel, 0, h->stream, h->st, sh, h->mu, h->cB, h->obj, h->basis, h->is_basic, h->touched,
-                       h->idx_upd, h->trace, h->trace_cap);
+                       h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
     LP_TRY(check_launch("k_rev_finish_pivot"));
   }
   return rev_enqueue_update(h);
@@ -243,7 +296,7 @@ int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
 int rev_enqueue_iteration(lpamd_rev_engine* h, int64_t ncols_active) {
   const RevShape& sh = h->sh;
   LP_TRY(rev_rowdot(h));
-  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost));
+  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost, true));
   LP_TRY(rev_enqueue_entering(h, false, ncols_active));
   return rev_enqueue_pivot_tail(h, -1);
 }
@@ -299,13 +352,16 @@ int rev_compute_optimum(lpamd_rev_engine* h) {
 int rev_init_basis(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
   HIP_TRY(hipMemsetAsync(h->BinvT, 0, sizeof(double) * (size_t)sh.m * sh.ldb, h->stream));
+  HIP_TRY(hipMemsetAsync(h->dense, 0, sh.ldb, h->stream));
+  HIP_TRY(hipMemsetAsync(h->pos, 0xFF, sizeof(int64_t) * sh.ldb, h->stream));
   hipLaunchKernelGGL(k_rev_init_basis, dim3((unsigned)((sh.m + 255) / 256)), dim3(256), 0, h->stream, sh, h->basis, h->rows, h->Trm,
-                     h->obj, h->BinvT, h->xB, h->cB);
+                     h->obj, h->BinvT, h->xB, h->cB, h->pos);
   LP_TRY(check_launch("k_rev_init_basis"));
   // an initial entry below the zero-drop threshold survives until the first update, which
   // therefore has to visit every row once
   LP_TRY(rev_pull(h));
   h->h_st.full_update = 1;
+  h->h_st.n_dense = 0;
   return rev_push(h);
 }
 
@@ -406,6 +462,8 @@ int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_str
   if (const char* env = getenv("LPAMD_REV_UPDATE_UNROLL")) h->force_update_unroll = atoi(env);
   if (const char* env = getenv("LPAMD_REV_SPLIT")) h->force_split = atoi(env);
   if (const char* env = getenv("LPAMD_REV_TILE")) h->force_tile = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_LIST")) h->list_rows = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_REV_UNIT")) h->unit_rows = atoi(env) != 0;
   *out = h;
   return LPAMD_OK;
 }

@@ -21,6 +21,11 @@
 //          LDS tiles so that the global loads stay coalesced.
 //   obj, cost  ldw doubles; xB, cB, pvec, mu, colbuf, scaled  ldb doubles;
 //   idx_upd  ldb int32: compacted list of the rows of BinvT the pending update has to touch.
+//   Unit rows.  The start basis is a signed permutation, so a row k of BinvT starts with one
+//   non-zero (at position pos[k]) and keeps that shape until an update lists it; `dense`
+//   (a byte per row) and idx_dense (ascending list) record the rows that have been listed.
+//   The two products over the inverse then run over the dense rows only and take the single
+//   term of a unit row directly, which is the same sum with its exact-zero terms left out.
 #pragma once
 #include "lpamd_kernels.hip.h"
 
@@ -35,6 +40,8 @@ struct RevState {      // device resident, one per revised engine
   int64_t leaving;     // leaving basis position
   double ratio;
   int32_t n_upd;       // entries of idx_upd
+  int32_t n_rows;      // entries of idx_rows (rows with a non-zero multiplier in the pricing product)
+  int32_t n_dense;     // entries of idx_dense (rows of BinvT an update has touched)
   int32_t pad0;
 };
 
@@ -135,22 +142,33 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
 // of 4096 / kW; all 256 lanes load the chunk (16 bytes each, eight loads in flight) while kW lanes
 // of the first wavefront add it up in row order.  Against one-lane-per-output this puts 4 to 16
 // times more loads in flight per output, which is what narrow or short matrices need; chunks
-// whose coefficients are all zero are skipped.
-template <int kW, bool kCost>
+// whose coefficients are all zero are skipped.  kListed: the rows are rows[0..*n_listed), the
+// ascending list of the rows with a non-zero coefficient (k_rev_list_nonzero), so that a
+// coefficient vector with few, scattered non-zeros costs only its own rows.
+// kUnit (with kListed): the list holds the dense rows of the transposed inverse; output j also takes the
+// single term of its unit row rowof[j] (if that row is still a unit row), merged at its place in the
+// ascending row order.
+template <int kW, bool kCost, bool kListed, bool kUnit = false>
 __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
-    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
-    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out) {
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows_all, int64_t ncols,
+    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out,
+    const int32_t* __restrict__ rows, const int32_t* __restrict__ n_listed,
+    const int64_t* __restrict__ rowof = nullptr, const uint8_t* __restrict__ dense = nullptr) {
   constexpr int kH = 4096 / kW;                    // rows per chunk
   constexpr int kRowsPerPass = 2 * kRevThreads / kW;
   constexpr int kPasses = kH / kRowsPerPass;       // = 8
   __shared__ double tile[kH * kW];
   __shared__ double s_coef[kH];
+  __shared__ int32_t s_row[kUnit ? kH : 1];
   if (st->status != ST_RUNNING) return;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int64_t j0 = (int64_t)blockIdx.x * kW;
   const int lrow = tid / (kW / 2), lcol = (tid % (kW / 2)) * 2;
+  const int64_t nrows = kListed ? (int64_t)*n_listed : nrows_all;   // positions in the list, or rows
   const int64_t nchunks = (nrows + kH - 1) / kH;
+  auto row_at = [&](int64_t pos) -> int64_t { return kListed ? (int64_t)rows[pos] : pos; };
   auto next_active = [&](int64_t c) {
+    if (kListed) return c;   // every listed row counts
     for (; c < nchunks; c++) {
       bool nz = false;
       for (int q = lane; q < kH; q += kWave) {
@@ -163,12 +181,23 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
   };
   double2 reg[kPasses];
   double creg[(kH + kRevThreads - 1) / kRevThreads];
+  int32_t rreg[(kH + kRevThreads - 1) / kRevThreads];
+  // the single term of this output's unit row, and the row it belongs to (INT32_MAX: none)
+  double uterm = 0.0;
+  int32_t urow = INT32_MAX;
+  if (kUnit && tid < kW && j0 + tid < ncols) {
+    const int64_t k = rowof[j0 + tid];
+    if (k >= 0 && !dense[k]) {
+      urow = (int32_t)k;
+      uterm = __dmul_rn(coef[k], M[k * ld + j0 + tid]);
+    }
+  }
   auto issue_loads = [&](int64_t c) {
 #pragma unroll
     for (int q = 0; q < kPasses; q++) {
-      const int64_t gr = c * kH + q * kRowsPerPass + lrow;
-      const double* src = M + gr * ld + j0 + lcol;
-      if (gr < nrows && j0 + lcol < ld) {
+      const int64_t pos = c * kH + q * kRowsPerPass + lrow;
+      if (pos < nrows && j0 + lcol < ld) {
+        const double* src = M + row_at(pos) * ld + j0 + lcol;
         reg[q].x = __builtin_nontemporal_load(src);
         reg[q].y = __builtin_nontemporal_load(src + 1);
       } else {
@@ -177,8 +206,10 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
     }
 #pragma unroll
     for (int q = 0; q * kRevThreads < kH; q++) {
-      const int64_t r = c * kH + q * kRevThreads + tid;
-      creg[q] = (q * kRevThreads + tid < kH && r < nrows) ? coef[r] : 0.0;
+      const int64_t pos = c * kH + q * kRevThreads + tid;
+      const bool in = q * kRevThreads + tid < kH && pos < nrows;
+      creg[q] = in ? coef[row_at(pos)] : 0.0;
+      rreg[q] = in ? (int32_t)row_at(pos) : INT32_MAX;
     }
   };
   double acc = 0.0;
@@ -191,16 +222,31 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
       *reinterpret_cast<double2*>(tile + (q * kRowsPerPass + lrow) * kW + lcol) = reg[q];
 #pragma unroll
     for (int q = 0; q * kRevThreads < kH; q++)
-      if (q * kRevThreads + tid < kH) s_coef[q * kRevThreads + tid] = creg[q];
+      if (q * kRevThreads + tid < kH) {
+        s_coef[q * kRevThreads + tid] = creg[q];
+        if (kUnit) s_row[q * kRevThreads + tid] = rreg[q];
+      }
     __syncthreads();
     const int64_t cn = next_active(c + 1);
     if (cn < nchunks) issue_loads(cn);
     if (tid < kW) {
+      if (kUnit) {
+#pragma unroll 8
+        for (int rr = 0; rr < kH; rr++) {
+          if (s_row[rr] > urow) {            // the unit row sorts before this dense row: its term goes in first
+            acc = __dadd_rn(acc, uterm);
+            urow = INT32_MAX;
+          }
+          acc = __dadd_rn(acc, __dmul_rn(s_coef[rr], tile[rr * kW + tid]));
+        }
+      } else {
 #pragma unroll 16
-      for (int rr = 0; rr < kH; rr++) acc = __dadd_rn(acc, __dmul_rn(s_coef[rr], tile[rr * kW + tid]));
+        for (int rr = 0; rr < kH; rr++) acc = __dadd_rn(acc, __dmul_rn(s_coef[rr], tile[rr * kW + tid]));
+      }
     }
     c = cn;
   }
+  if (kUnit && urow != INT32_MAX) acc = __dadd_rn(acc, uterm);   // the unit row sorts after every dense row
   const int64_t j = j0 + tid;
   if (tid < kW && j < ncols) out[j] = kCost ? flushz(__dadd_rn(base[j], acc)) : acc;
 }
@@ -212,10 +258,13 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
 // (odd pitch, conflict-free for the transposed read), and kR lanes of the first
 // wavefront add their row of the tile in order while the loads of the next chunk
 // are already in flight.  Chunks whose coefficients are all zero are skipped.
-template <int kR>
+// kListed: the workgroup's rows are rows[blockIdx.x * kR ..) of the list of *n_listed dense rows; the
+// other (unit) rows get their single term from k_rev_unit_rows_p.
+template <int kR, bool kListed>
 __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
-    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
-    const double* __restrict__ coef, double* __restrict__ out) {
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows_all, int64_t ncols,
+    const double* __restrict__ coef, double* __restrict__ out, const int32_t* __restrict__ rows,
+    const int32_t* __restrict__ n_listed) {
   constexpr int kC = 4096 / kR;
   constexpr int kPitch = kC + 1;
   constexpr int kRowsPerPass = 2 * kRevThreads / kC;
@@ -225,6 +274,9 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
   if (st->status != ST_RUNNING) return;
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const int64_t r0 = (int64_t)blockIdx.x * kR;
+  const int64_t nrows = kListed ? (int64_t)*n_listed : nrows_all;   // positions in the list, or rows
+  if (r0 >= nrows) return;
+  auto row_at = [&](int64_t pos) -> int64_t { return kListed ? (int64_t)rows[pos] : pos; };
   const int lrow = tid / (kC / 2), lcol = (tid % (kC / 2)) * 2;
   const int64_t nchunks = (ncols + kC - 1) / kC;
   auto next_active = [&](int64_t c) {   // same answer in every wavefront: they test the same data
@@ -240,13 +292,17 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
   };
   double2 reg[kPasses];
   double creg = 0.0;
+  int64_t grow[kPasses];   // matrix rows of this lane's tile rows (-1: past the end)
+#pragma unroll
+  for (int q = 0; q < kPasses; q++) {
+    const int64_t pos = r0 + q * kRowsPerPass + lrow;
+    grow[q] = pos < nrows ? row_at(pos) : -1;
+  }
   auto issue_loads = [&](int64_t c) {
     const int64_t col = c * kC + lcol;
 #pragma unroll
-    for (int q = 0; q < kPasses; q++) {
-      const int64_t gr = r0 + q * kRowsPerPass + lrow;
-      reg[q] = (gr < nrows && col < ld) ? *reinterpret_cast<const double2*>(M + gr * ld + col) : make_double2(0.0, 0.0);
-    }
+    for (int q = 0; q < kPasses; q++)
+      reg[q] = (grow[q] >= 0 && col < ld) ? *reinterpret_cast<const double2*>(M + grow[q] * ld + col) : make_double2(0.0, 0.0);
     if (tid < kC) creg = c * kC + tid < ncols ? coef[c * kC + tid] : 0.0;
   };
   double acc = 0.0;
@@ -271,7 +327,19 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
     }
     c = cn;
   }
-  if (tid < kR && r0 + tid < nrows) out[r0 + tid] = acc;
+  if (tid < kR && r0 + tid < nrows) out[row_at(r0 + tid)] = acc;
+}
+
+// p[r] for the rows of the transposed inverse that are still unit rows: the sum over the row has one
+// term that can be non-zero, c_B[pos[r]] * BinvT[r][pos[r]], and starts from +0.0.
+__global__ __launch_bounds__(kRevThreads) void k_rev_unit_rows_p(
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, const double* __restrict__ coef,
+    const int64_t* __restrict__ pos, const uint8_t* __restrict__ dense, double* __restrict__ out) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t r = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
+  if (r >= nrows || dense[r]) return;
+  const int64_t i = pos[r];
+  out[r] = i >= 0 ? __dadd_rn(0.0, __dmul_rn(coef[i], M[r * ld + i])) : 0.0;
 }
 
 // colbuf[r] = M[r * ld + col] for rows r = threadIdx.x, threadIdx.x + blockDim.x, ...; the strided
@@ -379,6 +447,29 @@ __device__ __forceinline__ void list_flagged(const uint8_t* __restrict__ bytes, 
   if (threadIdx.x == 0) *count = total;
 }
 
+// Ascending list of the indices i < n with v[i] != 0 (the rows a sparse coefficient vector makes a
+// column product read); one workgroup, every thread a contiguous run, loads eight at a time.
+__global__ __launch_bounds__(kRevSelectThreads) void k_rev_list_nonzero(
+    const RevState* __restrict__ st, const double* __restrict__ v, int64_t n, int32_t* __restrict__ idx, int32_t* __restrict__ count) {
+  __shared__ int s_w[kRevSelectThreads / kWave + 1];
+  if (st->status != ST_RUNNING) return;
+  const int64_t seg = (n + kRevSelectThreads - 1) / kRevSelectThreads;
+  const int64_t begin = threadIdx.x * seg, end = begin + seg < n ? begin + seg : n;
+  int hits = 0;
+  for (int64_t b = begin; b < end; b += 8) {
+    double x[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) x[q] = b + q < end ? v[b + q] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) hits += x[q] != 0.0;
+  }
+  int total;
+  int at = block_exclusive_scan(hits, s_w, total);
+  for (int64_t i = begin; i < end; i++)
+    if (v[i] != 0.0) idx[at++] = (int32_t)i;
+  if (threadIdx.x == 0) *count = total;
+}
+
 // Ratio test over mu = B^-1 * column (reference :282-297) and everything of the
 // pivot that is a vector operation (reference :42-60): the basic solution moves
 // along mu without a zero drop, the leaving row of the inverse (column `leaving`
@@ -395,7 +486,7 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
     RevState* __restrict__ st, RevShape sh, int64_t forced_leaving, double* __restrict__ mu, double* __restrict__ xB,
     double* __restrict__ cB, const double* __restrict__ obj, int64_t* __restrict__ basis, uint8_t* __restrict__ is_basic,
     const double* __restrict__ BinvT, double* __restrict__ scaled, int32_t* __restrict__ idx_upd, int64_t* __restrict__ trace,
-    int64_t trace_cap) {
+    int64_t trace_cap, uint8_t* __restrict__ dense, int32_t* __restrict__ idx_dense) {
   __shared__ double s_v[kRevSelectThreads / kWave];
   __shared__ int64_t s_i[kRevSelectThreads / kWave];
   __shared__ int s_w[kRevSelectThreads / kWave + 1];
@@ -459,7 +550,9 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
         xB[k] = k == l ? ratio : __dadd_rn(xk[q], __dmul_rn(mk[q], ratio));
         const double sc = __dmul_rn(old[q], s);
         scaled[k] = sc;
-        const bool hit = full || old[q] != 0.0 || sc != 0.0;
+        const bool changes = old[q] != 0.0 || sc != 0.0;   // the update makes this row dense
+        if (changes) dense[k] = 1;
+        const bool hit = full || changes;
         touched += hit;
         if (hit && k - k_begin < 64) mask |= 1ull << (k - k_begin);
       }
@@ -472,6 +565,8 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
                                       : (full || BinvT[k * sh.ldb + l] != 0.0 || scaled[k] != 0.0);
     if (hit) idx_upd[at++] = (int32_t)k;
   }
+  __syncthreads();
+  list_flagged(dense, sh.m, idx_dense, s_w, &st->n_dense);
   if (threadIdx.x == 0) {
     mu[l] = 0.0;
     is_basic[e] = 1;
@@ -492,7 +587,7 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
 // row of BinvT telling whether the update has to visit it.
 __global__ __launch_bounds__(kRevThreads) void k_rev_pivot_vectors(
     const RevState* __restrict__ st, RevShape sh, const double* __restrict__ mu, double* __restrict__ xB,
-    const double* __restrict__ BinvT, double* __restrict__ scaled, uint8_t* __restrict__ touched) {
+    const double* __restrict__ BinvT, double* __restrict__ scaled, uint8_t* __restrict__ touched, uint8_t* __restrict__ dense) {
   if (st->status != ST_RUNNING) return;
   const int64_t k = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
   if (k >= sh.m) return;
@@ -503,7 +598,9 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_pivot_vectors(
   xB[k] = k == l ? ratio : __dadd_rn(xB[k], __dmul_rn(mu[k], ratio));
   const double sc = __dmul_rn(old, s);
   scaled[k] = sc;
-  touched[k] = (st->full_update != 0 || old != 0.0 || sc != 0.0) ? 1 : 0;
+  const bool changes = old != 0.0 || sc != 0.0;   // the update makes this row dense
+  if (changes) dense[k] = 1;
+  touched[k] = (st->full_update != 0 || changes) ? 1 : 0;
 }
 
 // Closes the pivot after k_rev_pivot_vectors: list of the rows to update, mu[leaving] = 0,
@@ -511,11 +608,12 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_pivot_vectors(
 __global__ __launch_bounds__(kRevSelectThreads) void k_rev_finish_pivot(
     RevState* __restrict__ st, RevShape sh, double* __restrict__ mu, double* __restrict__ cB, const double* __restrict__ obj,
     int64_t* __restrict__ basis, uint8_t* __restrict__ is_basic, const uint8_t* __restrict__ touched, int32_t* __restrict__ idx_upd,
-    int64_t* __restrict__ trace, int64_t trace_cap) {
+    int64_t* __restrict__ trace, int64_t trace_cap, const uint8_t* __restrict__ dense, int32_t* __restrict__ idx_dense) {
   __shared__ int s_w[kRevSelectThreads / kWave + 1];
   if (st->status != ST_RUNNING) return;
   const int64_t e = st->e, it = st->iter, l = st->leaving;
   list_flagged(touched, sh.m, idx_upd, s_w, &st->n_upd);
+  list_flagged(dense, sh.m, idx_dense, s_w, &st->n_dense);
   if (threadIdx.x == 0) {
     mu[l] = 0.0;
     is_basic[e] = 1;
@@ -580,7 +678,7 @@ __global__ __launch_bounds__(kRevThreads, 2) void k_rev_update(
 // b / -v (reference :212-233).  BinvT is zero on entry.
 __global__ void k_rev_init_basis(RevShape sh, const int64_t* __restrict__ basis, const int64_t* __restrict__ rows,
                                  const double* __restrict__ Trm, const double* __restrict__ obj, double* __restrict__ BinvT,
-                                 double* __restrict__ xB, double* __restrict__ cB) {
+                                 double* __restrict__ xB, double* __restrict__ cB, int64_t* __restrict__ pos) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sh.m) return;
   const int64_t bcol = basis[i], r = rows[i];
@@ -591,6 +689,7 @@ __global__ void k_rev_init_basis(RevShape sh, const int64_t* __restrict__ basis,
     x = Trm[r * sh.ldw + sh.N] / (-v);
     const double inv = 1.0 / (-v);
     BinvT[r * sh.ldb + i] = inv;
+    pos[r] = i;   // the single non-zero of row r of the transposed inverse
   }
   xB[i] = x;
 }
