@@ -21,7 +21,7 @@ def assert_same_state(eng, rt):
     assert np.array_equal(bits(xB), bits(rt.xB)), "basic solution differs"
     assert np.array_equal(bits(cB), bits(rt.cB)), "basis cost differs"
     assert np.array_equal(bits(Binv), bits(rt.Binv)), "basis inverse differs"
-    assert np.array_equal(bits(BinvT), bits(np.ascontiguousarray(rt.Binv.T))), "transposed copy out of step"
+    assert np.array_equal(bits(BinvT), bits(np.ascontiguousarray(rt.Binv.T))), "transposed storage differs"
 
 
 def upload(lpamd, tab):
