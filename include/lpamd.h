@@ -155,6 +155,30 @@ int lpamd_apply_pivot(lpamd_engine* eng, int32_t strategy, int64_t e, int64_t r,
  *     calls lpamd_apply_pivot with e = r = -1 (they are read on the device). */
 int lpamd_select_candidate_device(lpamd_engine* eng, int32_t strategy, const void* cands_dev, int32_t world);
 int lpamd_export_column_or_zero(lpamd_engine* eng, void* xbuf_dev);
+/* Look-ahead variant for MAX_COST (reference lp_simplex_tableau.cc:188-227 + TableauPivot :10-52,
+ * same results): the exchange of pivot k+1 travels on a second stream while the rank-1 update
+ * of pivot k streams the shard, which takes both collectives off the critical path.  This
+ * works because the set-up of pivot k already leaves the objective row of iteration k+1, so
+ * every rank knows its next candidate before its update has run.  Per pivot, on the engine's
+ * stream unless stated otherwise:
+ * a. lpamd_lookahead_setup: ratio test on the delivered column `xbuf_dev` for the winner kept
+ *    by step d, then the set-up of the pivot (scalars, col', row', objective row, bookkeeping)
+ *    WITHOUT the rank-1 update;
+ * b. lpamd_lookahead_export: best local candidate of the NEXT iteration -> `cand_dev` (32-byte
+ *    record), and that column as the pending update will leave it -> `xlocal_dev` (the tableau
+ *    is not written; with no update pending the column is copied as stored);
+ * c. lpamd_lookahead_update: the rank-1 update of the pivot set up in step a;
+ * d. meanwhile, on `hip_stream` (ordered after step b by the caller): the caller all-gathers the
+ *    records, lpamd_lookahead_select folds them, keeps the winner inside the engine and fills
+ *    `xbuf_dev` with `xlocal_dev` on the winner's rank and zeros elsewhere; the caller
+ *    sum-all-reduces `xbuf_dev` as 64-bit integers and orders step a of the next pivot after it.
+ * A run starts with steps b and d.  All four calls are asynchronous; the exchange buffers
+ * hold lpamd_exchange_bytes(m) bytes. */
+int lpamd_lookahead_setup(lpamd_engine* eng, const void* xbuf_dev);
+int lpamd_lookahead_export(lpamd_engine* eng, void* cand_dev, void* xlocal_dev);
+int lpamd_lookahead_update(lpamd_engine* eng);
+int lpamd_lookahead_select(lpamd_engine* eng, const void* cands_dev, int32_t world, const void* xlocal_dev, void* xbuf_dev,
+                           void* hip_stream);
 /* Pivot budget of the step-wise loop: after max_pivots more pivots (< 0: no limit)
  * the device steps turn into no-ops.  Also re-arms a loop that hit its budget.
  * lpamd_poll reports LPAMD_LIMIT both while running and when the budget is

@@ -81,6 +81,8 @@ struct lpamd_engine {
   double* rhs_next = nullptr;   // right-hand side after the pivot being applied
   uint8_t* cand_next = nullptr; // pricing candidates after the pivot being applied
   Candidate* cand = nullptr;
+  Candidate* cand_la = nullptr;   // look-ahead exchange: winner of the next pivot, written on the exchange stream
+  bool update_pending = false;    // a pivot has been set up (k_pivot_finalize) and its rank-1 update is not enqueued yet
   double* part_v = nullptr;     // [2 * kMaxPartials]: pricing partials, then ratio partials
   int64_t* part_i = nullptr;
   int32_t n_price_part = 1, n_ratio_part = 1, n_row_blocks = 1;
@@ -353,9 +355,8 @@ int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, con
   return check_launch("k_ratio_partial");
 }
 
-// pivot set-up + row gather (one launch), then the rank-1 update
-int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override,
-                            bool fuse_pr = false) {
+// pivot set-up + row gather (one launch)
+int enqueue_finalize(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override) {
   const double* rv = e->part_v + kMaxPartials;
   const int64_t* ri = e->part_i + kMaxPartials;
   const int grid = e->n_row_blocks + e->n_price_part;   // column workgroups double as the next pricing partials
@@ -369,6 +370,13 @@ int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* can
                        e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next);
   LP_TRY(check_launch("k_pivot_finalize"));
   e->price_partials_fresh = true;
+  return LPAMD_OK;
+}
+
+// pivot set-up, then the rank-1 update
+int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* cand, const double* xcol, int64_t d_override,
+                            bool fuse_pr = false) {
+  LP_TRY(enqueue_finalize(e, find_row, cand, xcol, d_override));
   return enqueue_update(e, fuse_pr && e->fuse_pr_enabled);
 }
 
@@ -530,6 +538,8 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda, e->stream));
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
+  HIP_TRY(hipMalloc(&e->cand_la, sizeof(Candidate)));
+  HIP_TRY(hipMemsetAsync(e->cand_la, 0xFF, sizeof(Candidate), e->stream));   // gcol = -1: no candidate
   HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
   HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 3 * kMaxPartials));
   // partial reductions: 256 columns / 256 rows per workgroup, strided beyond kMaxPartials workgroups
@@ -550,7 +560,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->part_v, e->part_i, e->st, e->trace};
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1088,6 +1098,44 @@ int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r,
   e->apply_since_pull++;
   LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
   return enqueue_pivot(e, strategy == LPAMD_MAX_COST, e->cand, (const double*)xbuf_dev, -1, strategy == LPAMD_MAX_REDUCTION);
+}
+
+int lpamd_lookahead_export(lpamd_engine* e, void* cand_dev, void* xlocal_dev) {
+  CHECK_LOADED(e);
+  if (!cand_dev || !xlocal_dev) return set_err(LPAMD_E_ARG, "lookahead_export: null buffer");
+  LP_TRY(enqueue_pricing(e, LPAMD_MAX_COST, (Candidate*)cand_dev));
+  hipLaunchKernelGGL(k_export_lookahead, dim3((unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->sh, e->st,
+                     (const Candidate*)cand_dev, e->colp, e->rowp, e->update_pending ? 1 : 0, (double*)xlocal_dev);
+  return check_launch("k_export_lookahead");
+}
+
+int lpamd_lookahead_select(lpamd_engine* e, const void* cands_dev, int32_t world, const void* xlocal_dev, void* xbuf_dev,
+                           void* hip_stream) {
+  CHECK_LOADED(e);
+  if (!cands_dev || !xlocal_dev || !xbuf_dev || world != e->sh.world) return set_err(LPAMD_E_ARG, "lookahead_select: bad arguments");
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : e->stream;
+  hipLaunchKernelGGL(k_lookahead_select, dim3((unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, s, (const Candidate*)cands_dev,
+                     (int)world, e->sh, (const double*)xlocal_dev, e->cand_la, (double*)xbuf_dev);
+  return check_launch("k_lookahead_select");
+}
+
+int lpamd_lookahead_setup(lpamd_engine* e, const void* xbuf_dev) {
+  CHECK_LOADED(e);
+  if (!xbuf_dev) return set_err(LPAMD_E_ARG, "lookahead_setup: null exchange buffer");
+  if (e->update_pending) return set_err(LPAMD_E_STATE, "lookahead_setup: the previous pivot still waits for lpamd_lookahead_update");
+  e->apply_since_pull++;
+  LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
+  LP_TRY(enqueue_ratio_partial(e, false, e->cand_la, (const double*)xbuf_dev));
+  LP_TRY(enqueue_finalize(e, true, e->cand_la, (const double*)xbuf_dev, -1));
+  e->update_pending = true;
+  return LPAMD_OK;
+}
+
+int lpamd_lookahead_update(lpamd_engine* e) {
+  CHECK_LOADED(e);
+  if (!e->update_pending) return set_err(LPAMD_E_STATE, "lookahead_update: no pivot has been set up");
+  e->update_pending = false;
+  return enqueue_update(e, false);
 }
 
 int lpamd_poll(lpamd_engine* e, int32_t* result) {

@@ -618,6 +618,61 @@ __global__ __launch_bounds__(256) void k_export_or_zero(
   xbuf[i] = v;
 }
 
+// Look-ahead exchange (MAX_COST).  Once k_pivot_finalize has set a pivot up, the next
+// entering candidate of this rank is known (pricing partials on the updated objective
+// row) although the rank-1 update has not run yet.  This kernel writes that column AS
+// IT WILL BE after the pending update, T[:, l] (+) col' * row'[l] with the update's own
+// arithmetic, into `xlocal` without touching the tableau, so the exchange of the next
+// pivot column can travel while the update streams the shard.  pending == 0: no pivot
+// is waiting for its update (first iteration of a run), the column is copied as it is.
+__global__ __launch_bounds__(256) void k_export_lookahead(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand_local,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int pending, double* __restrict__ xlocal) {
+  if (st->status != ST_RUNNING) return;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sh.lda) return;
+  const int64_t e = cand_local->gcol;
+  double v = 0.0;
+  if (e >= 0 && i < sh.m) {
+    const int64_t l = ordinal_of(e, sh.N) / sh.world;   // the local candidate is a column of this rank
+    v = T.col(l)[i];
+    if (pending) {
+      const double rj = rowp[l];
+      if (rj != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(colp[i], rj)));   // k_update leaves columns with row' == 0 alone
+    }
+  }
+  xlocal[i] = v;
+}
+
+// Runs on the exchange stream, next to the update: folds the gathered records (largest
+// reduced cost, lowest global column on ties; reference lp_simplex_tableau.cc:188-198),
+// keeps the winner in `cand_la` and fills the exchange buffer with this rank's
+// look-ahead column if it owns the winner, with zeros otherwise (the integer
+// sum-all-reduce that follows hands every rank the exact column).  It reads nothing the
+// update writes and leaves the pivot state alone: "no candidate" travels as gcol = -1
+// and turns into SOLVED in the ratio-test kernel of the next pivot.
+__global__ __launch_bounds__(256) void k_lookahead_select(
+    const Candidate* __restrict__ recs, int world, Shape sh, const double* __restrict__ xlocal,
+    Candidate* __restrict__ cand_la, double* __restrict__ xbuf) {
+  __shared__ Candidate s_best;
+  if (threadIdx.x == 0) {
+    Candidate best;
+    best.key = -DBL_MAX; best.gcol = -1; best.row = -1; best.ce = 0.0;
+    for (int k = 0; k < world; k++) {
+      const Candidate c = recs[k];
+      if (c.gcol < 0) continue;
+      if (best.gcol < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) best = c;
+    }
+    s_best = best;
+    if (blockIdx.x == 0) *cand_la = best;
+  }
+  __syncthreads();
+  const int64_t e = s_best.gcol;
+  const bool mine = e >= 0 && ordinal_of(e, sh.N) % sh.world == sh.rank;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sh.lda) xbuf[i] = mine ? xlocal[i] : 0.0;
+}
+
 // --------------------------------------------------------------- utilities
 __global__ void k_gather_row(Tab T, int32_t ncl, int64_t r, double* __restrict__ out) {
   const int l = blockIdx.x * blockDim.x + threadIdx.x;

@@ -77,6 +77,10 @@ def library():
         "lpamd_set_pivot_budget": (ctypes.c_int, [vp, i64]),
         "lpamd_apply_pivot": (ctypes.c_int, [vp, i32, i64, i64, vp]),
         "lpamd_poll": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_lookahead_setup": (ctypes.c_int, [vp, vp]),
+        "lpamd_lookahead_export": (ctypes.c_int, [vp, vp, vp]),
+        "lpamd_lookahead_update": (ctypes.c_int, [vp]),
+        "lpamd_lookahead_select": (ctypes.c_int, [vp, vp, i32, vp, vp, vp]),
         "lpamd_fill_column": (ctypes.c_int, [vp, i64, ctypes.c_double]),
         "lpamd_set_basic_flag": (ctypes.c_int, [vp, i64, i32]),
         "lpamd_pivot_shard": (ctypes.c_int, [vp, i64, i64, i64, ctypes.c_double, vp]),
@@ -275,6 +279,21 @@ class TableauEngine:
         res = ctypes.c_int32()
         _ck(self.L.lpamd_poll(self.h, ctypes.byref(res)))
         return res.value
+
+    # look-ahead exchange (MAX_COST): set-up and update of a pivot as two calls, export of the
+    # next candidate column in between, fold + fill of the exchange buffer on a second stream
+    def lookahead_setup(self, xbuf_ptr):
+        _ck(self.L.lpamd_lookahead_setup(self.h, ctypes.c_void_p(xbuf_ptr)))
+
+    def lookahead_export(self, cand_ptr, xlocal_ptr):
+        _ck(self.L.lpamd_lookahead_export(self.h, ctypes.c_void_p(cand_ptr), ctypes.c_void_p(xlocal_ptr)))
+
+    def lookahead_update(self):
+        _ck(self.L.lpamd_lookahead_update(self.h))
+
+    def lookahead_select(self, cands_ptr, xlocal_ptr, xbuf_ptr, stream=None):
+        _ck(self.L.lpamd_lookahead_select(self.h, ctypes.c_void_p(cands_ptr), self.world, ctypes.c_void_p(xlocal_ptr),
+                                          ctypes.c_void_p(xbuf_ptr), ctypes.c_void_p(stream) if stream else None))
 
     def exchange_doubles(self):
         return int(self.L.lpamd_exchange_bytes(self.m)) // 8

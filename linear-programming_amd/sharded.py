@@ -9,6 +9,11 @@ main loop (reference lp_simplex_tableau.cc:181-377) needs two exchanges:
      every rank with the reference's lowest-index tie-break (pricing);
   2. broadcast of the entering column (m doubles) from the rank that owns it.
 
+With MAX_COST pricing both travel on a second stream while the previous pivot's
+rank-1 update streams the shard (look-ahead exchange): the set-up of a pivot
+already leaves the next objective row, so every rank knows its next candidate
+and can send that column as the pending update will leave it.
+
 Everything else (ratio test on the broadcast column against the local RHS
 replica, row gather, rank-1 update of the local shard) is rank-local and
 bit-identical across ranks, so no further traffic is needed.
@@ -55,6 +60,7 @@ class EngineShard:
         # so the shard brings an explicit side stream; callers run the exchange
         # steps under `with torch.cuda.stream(shard.stream)`.
         self.stream = stream if stream is not None else torch.cuda.Stream(device)
+        self.xstream = torch.cuda.Stream(device)     # exchange stream of the look-ahead loop
         self.eng = _eng.TableauEngine(m, N, rank, world, stream=self.stream.cuda_stream)
         self.m, self.N, self.rank, self.world = m, N, rank, world
 
@@ -90,6 +96,21 @@ class EngineShard:
 
     def poll(self):
         return self.eng.poll()
+
+    # ---- look-ahead exchange (MAX_COST) ----
+    def lookahead_setup(self, xbuf):
+        self.eng.lookahead_setup(xbuf.data_ptr())
+
+    def lookahead_export(self, cand, xlocal):
+        self.eng.lookahead_export(cand.data_ptr(), xlocal.data_ptr())
+
+    def lookahead_update(self):
+        self.eng.lookahead_update()
+
+    def lookahead_select(self, cands, xlocal, xbuf):
+        """Enqueued on torch's current stream (the exchange stream), not on the engine's."""
+        self.eng.lookahead_select(cands.data_ptr(), xlocal.data_ptr(), xbuf.data_ptr(),
+                                  torch.cuda.current_stream(self.device).cuda_stream)
 
     # ---- pieces of the feasibility phase (host vectors are numpy, indexed by global column) ----
     def owns(self, col):
@@ -152,7 +173,11 @@ class DistComm:
 class ShardedSolver:
     """Drives one shard per rank through the pivot loop.
 
-    exchange="allreduce" (default): no host round trip inside the loop.  Every rank
+    exchange="lookahead" (default): like "allreduce", and for MAX_COST the two collectives
+    of pivot k+1 run on the shard's exchange stream while the rank-1 update of pivot k
+    streams the tableau, so the critical path of a pivot holds no collective at all
+    (MAX_REDUCTION prices on the updated columns and keeps the in-order exchange).
+    exchange="allreduce": no host round trip inside the loop.  Every rank
     folds the gathered candidates on the device; the pivot column travels as a
     64-bit-integer sum-all-reduce in which only its owner contributes non-zero
     words, so the root never has to be known on the host.  The host only polls the
@@ -161,8 +186,8 @@ class ShardedSolver:
     the owner and broadcasts the column from it.
     """
 
-    def __init__(self, shard, group=None, exchange="allreduce", poll_every=64, comm=None):
-        assert exchange in ("allreduce", "broadcast")
+    def __init__(self, shard, group=None, exchange="lookahead", poll_every=64, comm=None):
+        assert exchange in ("lookahead", "allreduce", "broadcast")
         self.shard = shard
         if comm is None and dist.is_available() and dist.is_initialized():
             comm = DistComm(group)               # collectives also run for a world of one
@@ -177,6 +202,10 @@ class ShardedSolver:
         self.cands = shard.new_buffer(4 * self.world)
         self.xbuf = shard.new_buffer(shard.exchange_doubles())
         self.xbuf_words = self.xbuf.view(torch.int64)
+        self.xlocal = shard.new_buffer(shard.exchange_doubles())    # look-ahead: this rank's next candidate column
+        self.ev_sent = self.ev_arrived = None
+        if self.xbuf.is_cuda and getattr(shard, "xstream", None) is not None:
+            self.ev_sent, self.ev_arrived = torch.cuda.Event(), torch.cuda.Event()
         if self.xbuf.is_cuda:
             # the zero-fills above ran on the allocating stream; the loop uses the shard's own stream
             torch.cuda.synchronize(self.xbuf.device)
@@ -184,7 +213,12 @@ class ShardedSolver:
 
     def run_pivots(self, strategy, k):
         """At most k pivots (k < 0: until termination).  Returns (Result, pivots done)."""
-        run = self._run_allreduce if self.exchange == "allreduce" else self._run_broadcast
+        if self.exchange == "broadcast":
+            run = self._run_broadcast
+        elif self.exchange == "lookahead" and strategy == _eng.MAX_COST:
+            run = self._run_lookahead
+        else:
+            run = self._run_allreduce
         stream = getattr(self.shard, "stream", None)
         if stream is None:
             return run(strategy, k)
@@ -216,6 +250,52 @@ class ShardedSolver:
             res = sh.poll()                  # the only host synchronisation
             if res != _eng.LIMIT or (k >= 0 and enqueued >= k):
                 break
+        return res, sh.pivot_count() - start
+
+    def _lookahead_exchange(self):
+        """Exchange for the NEXT pivot: gather the records, keep the winner, deliver its column.
+        With two streams it is ordered after what the loop stream holds so far (the export of
+        the local candidate) and runs beside what the loop stream gets next (the update)."""
+        sh = self.shard
+        if self.ev_sent is None:
+            self._gather_candidates()
+            sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
+            if self.use_dist:
+                self.comm.all_reduce_sum_words(self.xbuf_words)
+            return
+        self.ev_sent.record(sh.stream)
+        sh.xstream.wait_event(self.ev_sent)
+        with torch.cuda.stream(sh.xstream):
+            self._gather_candidates()
+            sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
+            if self.use_dist:
+                self.comm.all_reduce_sum_words(self.xbuf_words)
+            self.ev_arrived.record(sh.xstream)
+
+    def _run_lookahead(self, strategy, k):
+        assert strategy == _eng.MAX_COST
+        sh = self.shard
+        start = sh.pivot_count()
+        sh.set_pivot_budget(k)
+        two_streams = self.ev_sent is not None
+        sh.lookahead_export(self.cand, self.xlocal)      # nothing pending: the column as stored
+        self._lookahead_exchange()
+        enqueued = 0
+        while True:
+            n = self.poll_every if k < 0 else min(self.poll_every, k - enqueued)
+            for _ in range(n):
+                if two_streams:
+                    sh.stream.wait_event(self.ev_arrived)
+                sh.lookahead_setup(self.xbuf)                 # ratio test + set-up of this pivot
+                sh.lookahead_export(self.cand, self.xlocal)   # next candidate, as the pending update will leave it
+                self._lookahead_exchange()                    # ... travels while ...
+                sh.lookahead_update()                         # ... the rank-1 update streams the shard
+            enqueued += n
+            res = sh.poll()
+            if res != _eng.LIMIT or (k >= 0 and enqueued >= k):
+                break
+        if two_streams:
+            sh.stream.wait_event(self.ev_arrived)        # the last exchange is not consumed; keep the streams ordered
         return res, sh.pivot_count() - start
 
     def _run_broadcast(self, strategy, k):

@@ -18,6 +18,7 @@ ap.add_argument("--m", type=int, default=32768)
 ap.add_argument("--n", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--strategy", default="max_cost")
+ap.add_argument("--exchange", default="lookahead", choices=["lookahead", "allreduce"])
 args = ap.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -32,9 +33,37 @@ cands = shard.new_buffer(4 * G)
 cands.view(torch.int64)[1::4] = -1          # other ranks: no candidate
 xbuf = shard.new_buffer(shard.exchange_doubles())
 one = shard.new_buffer(4)
+xlocal = shard.new_buffer(shard.exchange_doubles())
+ev_sent, ev_arrived = torch.cuda.Event(), torch.cuda.Event()
 torch.cuda.synchronize()
 
+def exchange_ahead():
+    ev_sent.record(shard.stream)
+    shard.xstream.wait_event(ev_sent)
+    with torch.cuda.stream(shard.xstream):
+        dist.all_gather_into_tensor(one, cand)
+        cands[:4].copy_(one)
+        shard.lookahead_select(cands, xlocal, xbuf)
+        dist.all_reduce(xbuf.view(torch.int64))
+        ev_arrived.record(shard.xstream)
+
+def run_lookahead(k):
+    with torch.cuda.stream(shard.stream):
+        shard.set_pivot_budget(k)
+        shard.lookahead_export(cand, xlocal)
+        exchange_ahead()
+        for _ in range(k):
+            shard.stream.wait_event(ev_arrived)
+            shard.lookahead_setup(xbuf)
+            shard.lookahead_export(cand, xlocal)
+            exchange_ahead()
+            shard.lookahead_update()
+        shard.stream.wait_event(ev_arrived)
+        return shard.poll()
+
 def run(k):
+    if args.exchange == "lookahead" and args.strategy == "max_cost":
+        return run_lookahead(k)
     with torch.cuda.stream(shard.stream):
         shard.set_pivot_budget(k)
         for _ in range(k):

@@ -45,6 +45,8 @@ class HostShard:
         self.winner = None
         self.trace = []
         self.budget_end = None
+        self.pending = None                     # look-ahead loop: (col', row', RHS factor) of a pivot whose update is due
+        self.la_winner = None
 
     # ---- interface of EngineShard ----
     def exchange_doubles(self):
@@ -146,6 +148,11 @@ class HostShard:
         self._pivot(int(self.basis[r]), e, r, float(self.winner[3]), col)
 
     def _pivot(self, d, e, r, ce, col):
+        self._pivot_setup(d, e, r, ce, col)
+        self._pivot_update()
+
+    def _pivot_setup(self, d, e, r, ce, col):
+        """Everything of TableauPivot except the rank-1 update of the tableau and the RHS."""
         a = col[r]
         f = -1.0 / a
         g = ce * f
@@ -155,8 +162,7 @@ class HostShard:
         self.obj_const = float(flush(self.obj_const + self.rhs[r] * g))
         colp = col.copy()
         colp[r] = 1.0 + a
-        self.T = np.asfortranarray(flush(self.T + colp[:, None] * rowp[None, :]))
-        self.rhs = flush(self.rhs + colp * rhs_rowp)
+        self.pending = (colp, rowp, rhs_rowp)
         for l, gc in enumerate(self.gcols):
             if gc == e:
                 self.obj[l] = 0.0
@@ -165,6 +171,59 @@ class HostShard:
                 self.basic[l] = 0
         self.basis[r] = e
         self.trace.append((int(e), int(r)))
+
+    def _pivot_update(self):
+        colp, rowp, rhs_rowp = self.pending
+        self.pending = None
+        self.T = np.asfortranarray(flush(self.T + colp[:, None] * rowp[None, :]))
+        self.rhs = flush(self.rhs + colp * rhs_rowp)
+
+    # ---- look-ahead exchange (MAX_COST), same four steps as EngineShard ----
+    def lookahead_export(self, cand, xlocal):
+        x = xlocal.numpy()
+        x[:] = 0.0
+        if self.status != eng.LIMIT:
+            return
+        self.local_candidate(eng.MAX_COST, cand)
+        e = int(cand.numpy().view(np.int64)[1])
+        if e < 0:
+            return
+        l = self._local(e)
+        col = np.array(self.T[:, l], dtype=np.float64)
+        if self.pending is not None:
+            colp, rowp, _ = self.pending
+            if rowp[l] != 0.0:
+                col = flush(col + colp * rowp[l])
+        x[: self.m] = col
+
+    def lookahead_select(self, cands, xlocal, xbuf):
+        e, r, owner, res, win = eng.fold_candidates(eng.MAX_COST, cands.numpy(), self.world, self.N)
+        self.la_winner = win if res == eng.LIMIT else None
+        x = xbuf.numpy()
+        x[:] = xlocal.numpy() if (res == eng.LIMIT and owner == self.rank) else 0.0
+
+    def lookahead_setup(self, xbuf):
+        assert self.pending is None
+        if self.status != eng.LIMIT:
+            return
+        if self.budget_end is not None and len(self.trace) >= self.budget_end:
+            return
+        if self.la_winner is None:
+            self.status = eng.SOLVED
+            return
+        e = int(self.la_winner.view(np.int64)[1])
+        col = np.array(xbuf.numpy()[: self.m], dtype=np.float64)
+        rows = np.nonzero(f32(col) <= np.float32(-1e-6))[0]
+        if not len(rows):
+            self.status = eng.UNBOUNDED
+            return
+        ratios = self.rhs[rows] / (-col[rows])
+        r = int(rows[int(np.argmin(ratios))])
+        self._pivot_setup(int(self.basis[r]), e, r, float(self.la_winner[3]), col)
+
+    def lookahead_update(self):
+        if self.pending is not None:
+            self._pivot_update()
 
     # ---- pieces of the feasibility phase ----
     def owns(self, col):

@@ -50,6 +50,9 @@ def _worker(rank, world, port, case, strategy_name, out_dir, exchange):
 
 @pytest.mark.parametrize("case,strategy,exchange", [
     (("synthetic", 40, 90, 1), "max_cost", "allreduce"),
+    (("synthetic", 40, 90, 1), "max_cost", "lookahead"),
+    (("synthetic", 37, 70, 5), "max_cost", "lookahead"),
+    (("synthetic", 40, 90, 2), "max_reduction", "lookahead"),
     (("synthetic", 40, 90, 2), "max_reduction", "allreduce"),
     (("synthetic", 33, 64, 3), "max_cost", "broadcast"),
     (("synthetic", 33, 64, 3), "max_reduction", "broadcast"),
@@ -96,6 +99,7 @@ def _solve_worker(rank, world, port, name, strategy_name, out_dir, exchange):
 @pytest.mark.parametrize("name,strategy,exchange,world", [
     ("test15", "max_cost", "allreduce", 2), ("test16", "max_reduction", "broadcast", 2),
     ("afiro", "max_cost", "allreduce", 3), ("test17", "max_reduction", "allreduce", 2),
+    ("test15", "max_cost", "lookahead", 2), ("afiro", "max_cost", "lookahead", 3), ("test16", "max_cost", "lookahead", 2),
 ])
 def test_sharded_solve_with_feasibility_phase_matches_oracle_and_golden(tmp_path, name, strategy, exchange, world):
     """TableauSimplexSolve over shards, feasibility phase included: every rank walks the oracle's

@@ -165,7 +165,7 @@ def test_phase1_is_rejected_on_shards(lpamd):
         e.solve(eng.MAX_COST)
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "broadcast"])
+@pytest.mark.parametrize("exchange", ["lookahead", "allreduce", "broadcast"])
 def test_rccl_collectives_single_rank(lpamd, exchange):
     """World of one over the nccl (= RCCL) backend: the all-gather and the broadcast
     of the sharded loop run for real on the GPU."""
@@ -265,6 +265,8 @@ def solve_in_threads(lpamd, tab, world, strategy, exchange):
     ("test15", "max_cost", "allreduce", 2), ("test16", "max_reduction", "allreduce", 3),
     ("afiro", "max_cost", "broadcast", 2), ("kb2", "max_reduction", "allreduce", 2),
     ("adlittle", "max_cost", "allreduce", 4),
+    ("test15", "max_cost", "lookahead", 2), ("afiro", "max_cost", "lookahead", 3), ("adlittle", "max_cost", "lookahead", 4),
+    ("israel", "max_cost", "lookahead", 2),
 ])
 def test_sharded_solve_with_feasibility_phase_on_gpu(lpamd, name, strategy, exchange, world):
     """TableauSimplexSolve over real engine shards (one solver thread per rank on this GPU, in-process
@@ -289,11 +291,12 @@ def test_sharded_solve_reports_infeasible_and_unbounded(lpamd):
                        ("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n", lo.UNBOUNDED)):
         tab, dt = lo.from_text(text)
         assert dt.solve(lo.MAX_COST) == want
-        for res, done, trace, x, oc, rhs in solve_in_threads(lpamd, tab, 2, "max_cost", "allreduce"):
-            assert res == want and trace == dt.trace()
+        for exchange in ("allreduce", "lookahead"):
+            for res, done, trace, x, oc, rhs in solve_in_threads(lpamd, tab, 2, "max_cost", exchange):
+                assert res == want and trace == dt.trace()
 
 
-@pytest.mark.parametrize("exchange", ["allreduce", "broadcast"])
+@pytest.mark.parametrize("exchange", ["lookahead", "allreduce", "broadcast"])
 def test_rccl_single_rank_solve_with_feasibility_phase(lpamd, exchange):
     """The same solve over the nccl (= RCCL) backend with a world of one."""
     import socket
@@ -321,3 +324,62 @@ def test_rccl_single_rank_solve_with_feasibility_phase(lpamd, exchange):
         assert fe.format_solution(tab, x, shard.eng.objective_constant()).rstrip("\n") == case_golden("israel", "max_cost").rstrip("\n")
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_lookahead_exchange_overlaps_update_bit_exact(lpamd, world):
+    """Look-ahead loop on shards large enough that the exchange stream really runs beside the
+    rank-1 update (one solver thread per rank on this GPU): trace, tableau and RHS replicas
+    must equal the single-engine device loop bit for bit, across two budgeted legs."""
+    import threading
+    sharded = importlib.import_module("linear-programming_amd.sharded")
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    m, n, seed, legs = 1536, 3072, 7, (23, 40)
+    ref = lpamd.TableauEngine(m, n + m)
+    ref.fill_synthetic(n, seed)
+    assert ref.run_pivots(eng.MAX_COST, sum(legs)) == (eng.LIMIT, sum(legs))
+    Tref, oref, bref = ref.download()
+    shared = {"barrier": threading.Barrier(world), "slots": [None] * world}
+    out, errors = [None] * world, []
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            shard = sharded.EngineShard(m, n + m, rank, world, dev)
+            shard.eng.fill_synthetic(n, seed)
+            solver = sharded.ShardedSolver(shard, exchange="lookahead", poll_every=16,
+                                           comm=ThreadComm(shared, rank, world) if world > 1 else None)
+            for k in legs:
+                assert solver.run_pivots(eng.MAX_COST, k) == (eng.LIMIT, k)
+            torch.cuda.synchronize()
+            T = np.zeros((m, n + m + 2), order="F")
+            obj = np.zeros(n + m + 2)
+            basic = np.zeros(n + m + 2, dtype=np.uint8)
+            shard.eng.L.lpamd_download(shard.eng.h, T.ctypes.data, m, obj.ctypes.data, basic.ctypes.data)
+            out[rank] = (shard.eng.trace(), T, obj, basic)
+            shard.eng.close()
+        except BaseException as ex:   # noqa: B036 - reported by the caller
+            errors.append((rank, repr(ex)))
+            shared["barrier"].abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=150)
+    assert not errors, errors
+    T = np.zeros_like(Tref)
+    obj = np.zeros_like(oref)
+    N = n + m
+    for rank, (trace, Tr, objr, _) in enumerate(out):
+        assert trace == ref.trace()
+        own = [g for g in range(N + 2) if g != N and (g if g < N else N) % world == rank]
+        T[:, own] = Tr[:, own]
+        obj[own] = objr[own]
+        assert np.array_equal(bits(Tr[:, N]), bits(Tref[:, N])), "RHS replica diverged"
+        assert bits(objr[N:N + 1])[0] == bits(oref[N:N + 1])[0]
+    T[:, N] = Tref[:, N]
+    obj[N] = oref[N]
+    assert np.array_equal(bits(T), bits(Tref)) and np.array_equal(bits(obj), bits(oref))
