@@ -214,10 +214,10 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
 // p = c_B^T * B^-1: a dot product along every row of the transposed inverse
 int rev_rowdot(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
-  // 64 rows per workgroup need m / 64 >= 256 workgroups to fill the chip; below that 16 rows
-  // (16-row tiles for a short dense-row list were tried and lost: the 256-step chains per chunk cost
-  // more than the shorter load waits gain, 0.42 against 0.36 ms per pivot.)
-  const bool rows64 = h->force_rowdot_rows ? h->force_rowdot_rows == 64 : sh.m >= 16384;
+  // 16 rows per workgroup: the list of dense rows is short for thousands of pivots, and 16-row tiles put
+  // four times as many workgroups on it as 64-row tiles (m=32768 n=65536 after 3000 pivots: 0.66 against
+  // 0.90 ms per pivot; the first pivots do not care).  LPAMD_REV_ROWDOT_ROWS=64 keeps the wide variant.
+  const bool rows64 = h->force_rowdot_rows == 64;
   const int kr = rows64 ? 64 : 16;
   const dim3 grid((unsigned)((sh.m + kr - 1) / kr)), block(kRevThreads);
   const int32_t* rows = h->unit_rows ? h->idx_dense : nullptr;

@@ -257,7 +257,12 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
 // kR x kC tile with coalesced 16-byte accesses into registers, park it in LDS
 // (odd pitch, conflict-free for the transposed read), and kR lanes of the first
 // wavefront add their row of the tile in order while the loads of the next chunk
-// are already in flight.  Chunks whose coefficients are all zero are skipped.
+// are already in flight (two chunks are kept in flight).  Chunks whose coefficients are
+// all zero are skipped (their list is tabulated up front, so no test sits between two
+// chunks), and inside a chunk the adding lanes walk only the positions with a non-zero coefficient
+// (compacted in LDS, ascending): the basis costs are non-zero only at the positions that
+// hold a structural variable, so the sequential chain of a row has as many steps as
+// such positions, not m.
 // kListed: the workgroup's rows are rows[blockIdx.x * kR ..) of the list of *n_listed dense rows; the
 // other (unit) rows get their single term from k_rev_unit_rows_p.
 template <int kR, bool kListed>
@@ -266,66 +271,119 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
     const double* __restrict__ coef, double* __restrict__ out, const int32_t* __restrict__ rows,
     const int32_t* __restrict__ n_listed) {
   constexpr int kC = 4096 / kR;
+  constexpr int kCWaves = kC / kWave;
+  constexpr int kWaves = kRevThreads / kWave;
   constexpr int kPitch = kC + 1;
   constexpr int kRowsPerPass = 2 * kRevThreads / kC;
   constexpr int kPasses = kR / kRowsPerPass;
+  constexpr int kSeg = 2048;            // chunks whose activity is tabulated at a time
+  static_assert(kC >= kWave && kC <= kRevThreads, "one coefficient per lane");
   __shared__ double tile[kR * kPitch];
-  __shared__ double s_coef[kC];
+  __shared__ double s_cval[kC];
+  __shared__ int32_t s_cidx[kC];
+  __shared__ int32_t s_wcnt[kCWaves];
+  __shared__ uint8_t s_flag[kSeg];
+  __shared__ int32_t s_list[kSeg];      // ascending list of the segment's chunks with a non-zero coefficient
+  __shared__ int32_t s_nlist;
   if (st->status != ST_RUNNING) return;
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
   const int64_t r0 = (int64_t)blockIdx.x * kR;
   const int64_t nrows = kListed ? (int64_t)*n_listed : nrows_all;   // positions in the list, or rows
   if (r0 >= nrows) return;
   auto row_at = [&](int64_t pos) -> int64_t { return kListed ? (int64_t)rows[pos] : pos; };
   const int lrow = tid / (kC / 2), lcol = (tid % (kC / 2)) * 2;
   const int64_t nchunks = (ncols + kC - 1) / kC;
-  auto next_active = [&](int64_t c) {   // same answer in every wavefront: they test the same data
-    for (; c < nchunks; c++) {
-      bool nz = false;
-      for (int q = lane; q < kC; q += kWave) {
-        const int64_t i = c * kC + q;
-        nz |= i < ncols && coef[i] != 0.0;
-      }
-      if (__ballot(nz) != 0) break;
-    }
-    return c;
-  };
-  double2 reg[kPasses];
-  double creg = 0.0;
+  double2 ra[kPasses], rb[kPasses];
+  double ca = 0.0, cb = 0.0;
   int64_t grow[kPasses];   // matrix rows of this lane's tile rows (-1: past the end)
 #pragma unroll
   for (int q = 0; q < kPasses; q++) {
     const int64_t pos = r0 + q * kRowsPerPass + lrow;
     grow[q] = pos < nrows ? row_at(pos) : -1;
   }
-  auto issue_loads = [&](int64_t c) {
+  auto issue = [&](double2 (&reg)[kPasses], double& cr, int64_t c) {
     const int64_t col = c * kC + lcol;
 #pragma unroll
     for (int q = 0; q < kPasses; q++)
       reg[q] = (grow[q] >= 0 && col < ld) ? *reinterpret_cast<const double2*>(M + grow[q] * ld + col) : make_double2(0.0, 0.0);
-    if (tid < kC) creg = c * kC + tid < ncols ? coef[c * kC + tid] : 0.0;
+    if (tid < kC) cr = c * kC + tid < ncols ? coef[c * kC + tid] : 0.0;
   };
   double acc = 0.0;
-  int64_t c = next_active(0);
-  if (c < nchunks) issue_loads(c);
-  while (c < nchunks) {
-    __syncthreads();   // the previous tile has been consumed
+  // parks a chunk in LDS, compacts its non-zero coefficients in order and adds the listed terms
+  auto consume = [&](const double2 (&reg)[kPasses], double cr, auto&& refill) {
+    __syncthreads();   // the previous tile and its coefficient list have been consumed
 #pragma unroll
     for (int q = 0; q < kPasses; q++) {
       double* dst = tile + (q * kRowsPerPass + lrow) * kPitch + lcol;
       dst[0] = reg[q].x;
       dst[1] = reg[q].y;
     }
-    if (tid < kC) s_coef[tid] = creg;
+    const bool nz = tid < kC && cr != 0.0;
+    const unsigned long long mask = __ballot(nz);
+    if (tid < kC && lane == 0) s_wcnt[wave] = __popcll(mask);
     __syncthreads();
-    const int64_t cn = next_active(c + 1);
-    if (cn < nchunks) issue_loads(cn);
+    int before = 0, n_terms = 0;
+#pragma unroll
+    for (int w = 0; w < kCWaves; w++) {
+      const int n = s_wcnt[w];
+      if (w < wave) before += n;
+      n_terms += n;
+    }
+    if (nz) {
+      const int at = before + __popcll(mask & ((1ull << lane) - 1ull));
+      s_cidx[at] = tid;
+      s_cval[at] = cr;
+    }
+    __syncthreads();
+    refill();          // the registers are free again: the loads of the chunk after next go out before the adds
     if (tid < kR) {
       const double* row = tile + tid * kPitch;
-#pragma unroll 16
-      for (int b = 0; b < kC; b++) acc = __dadd_rn(acc, __dmul_rn(s_coef[b], row[b]));
+#pragma unroll 4
+      for (int b = 0; b < n_terms; b++) acc = __dadd_rn(acc, __dmul_rn(s_cval[b], row[s_cidx[b]]));
     }
-    c = cn;
+  };
+  for (int64_t seg0 = 0; seg0 < nchunks; seg0 += kSeg) {
+    const int nseg = (int)(nchunks - seg0 < kSeg ? nchunks - seg0 : kSeg);
+    // which chunks of the segment hold a non-zero coefficient: a wavefront tests four chunks per round trip
+    __syncthreads();   // the list of the previous segment has been consumed
+    for (int ch0 = wave * 4; ch0 < nseg; ch0 += kWaves * 4) {
+      bool nzc[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        nzc[u] = false;
+#pragma unroll
+        for (int q = 0; q < kCWaves; q++) {
+          const int64_t i = (seg0 + ch0 + u) * kC + q * kWave + lane;
+          nzc[u] |= ch0 + u < nseg && i < ncols && coef[i] != 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const bool any = __ballot(nzc[u]) != 0;
+        if (lane == 0 && ch0 + u < nseg) s_flag[ch0 + u] = any ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {   // ordered compaction of the flags
+      int n = 0;
+      for (int b = 0; b < nseg; b += kWave) {
+        const bool f = b + lane < nseg && s_flag[b + lane] != 0;
+        const unsigned long long mask = __ballot(f);
+        if (f) s_list[n + __popcll(mask & ((1ull << lane) - 1ull))] = b + lane;
+        n += __popcll(mask);
+      }
+      if (lane == 0) s_nlist = n;
+    }
+    __syncthreads();
+    const int nl = s_nlist;
+    // two chunks in flight: while one is parked in LDS and added up, the loads of the next are under way
+    if (nl > 0) issue(ra, ca, seg0 + s_list[0]);
+    if (nl > 1) issue(rb, cb, seg0 + s_list[1]);
+    for (int k = 0; k < nl; k += 2) {
+      consume(ra, ca, [&]() { if (k + 2 < nl) issue(ra, ca, seg0 + s_list[k + 2]); });
+      if (k + 1 >= nl) break;
+      consume(rb, cb, [&]() { if (k + 3 < nl) issue(rb, cb, seg0 + s_list[k + 3]); });
+    }
   }
   if (tid < kR && r0 + tid < nrows) out[row_at(r0 + tid)] = acc;
 }
