@@ -30,6 +30,13 @@ struct lpamd_rev_engine {
   uint8_t* dense = nullptr;     // the same as a byte per row
   int64_t* pos = nullptr;       // row of BinvT -> position of its single start entry (-1: none)
   uint8_t* touched = nullptr;   // one byte per row of BinvT: the pending update visits it
+  int32_t* cnt_touched = nullptr;   // per 256 rows: flagged entries of touched / dense / non-zeros of p, the
+  int32_t* cnt_dense = nullptr;     // first half of the chip-wide ordered lists
+  int32_t* cnt_p = nullptr;
+  double* sel_v = nullptr;      // pricing partials of the cost product, one per workgroup
+  int64_t* sel_i = nullptr;
+  int32_t sel_parts = 0;        // partials the last cost product left (0: none)
+  bool p_counted = false;       // cnt_p describes pvec
   RevState* st = nullptr;
   int64_t* trace = nullptr;
   int64_t trace_cap = 0;
@@ -51,6 +58,8 @@ struct lpamd_rev_engine {
   bool list_rows = true;
   // LPAMD_REV_UNIT=0: the products over the inverse read every row instead of the dense rows only
   bool unit_rows = true;
+  // LPAMD_REV_WIDE=0: ordered lists and the pricing arg-min in single workgroups instead of chip-wide
+  bool wide = true;
   bool split() const { return force_split >= 0 ? force_split != 0 : sh.m > 8192; }
 };
 
@@ -64,7 +73,8 @@ namespace {
 
 void rev_free(lpamd_rev_engine* h) {
   void* ptrs[] = {h->Trm, h->BinvT, h->obj, h->cost, h->is_basic, h->negate, h->basis, h->rows, h->xB,
-                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_upd, h->idx_rows, h->idx_dense, h->dense, h->pos, h->touched, h->st, h->trace};
+                  h->cB, h->pvec, h->mu, h->colbuf, h->scaled, h->idx_upd, h->idx_rows, h->idx_dense, h->dense, h->pos, h->touched, h->st, h->trace,
+                  h->cnt_touched, h->cnt_dense, h->cnt_p, h->sel_v, h->sel_i};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   h->Trm = h->BinvT = h->obj = h->cost = h->xB = h->cB = h->pvec = h->mu = h->colbuf = h->scaled = nullptr;
@@ -73,6 +83,11 @@ void rev_free(lpamd_rev_engine* h) {
   h->idx_upd = h->idx_rows = h->idx_dense = nullptr;
   h->dense = nullptr;
   h->pos = nullptr;
+  h->cnt_touched = h->cnt_dense = h->cnt_p = nullptr;
+  h->sel_v = nullptr;
+  h->sel_i = nullptr;
+  h->sel_parts = 0;
+  h->p_counted = false;
   h->st = nullptr;
   h->trace_cap = 0;
 }
@@ -102,6 +117,12 @@ int rev_allocate(lpamd_rev_engine* h, int64_t W) {
   HIP_TRY(hipMalloc(&h->dense, sh.ldb));
   HIP_TRY(hipMalloc(&h->pos, sizeof(int64_t) * sh.ldb));
   HIP_TRY(hipMalloc(&h->touched, sh.ldb));
+  const size_t nblk = (size_t)(sh.ldb + kRevThreads - 1) / kRevThreads, nparts = (size_t)(sh.ldw + 15) / 16;
+  HIP_TRY(hipMalloc(&h->cnt_touched, sizeof(int32_t) * nblk));
+  HIP_TRY(hipMalloc(&h->cnt_dense, sizeof(int32_t) * nblk));
+  HIP_TRY(hipMalloc(&h->cnt_p, sizeof(int32_t) * nblk));
+  HIP_TRY(hipMalloc(&h->sel_v, sizeof(double) * nparts));
+  HIP_TRY(hipMalloc(&h->sel_i, sizeof(int64_t) * nparts));
   double** vecs[] = {&h->xB, &h->cB, &h->pvec, &h->mu, &h->colbuf, &h->scaled};
   for (double** v : vecs) {
     HIP_TRY(hipMalloc(v, sizeof(double) * sh.ldb));
@@ -158,8 +179,12 @@ int rev_upload_obj(lpamd_rev_engine* h) {
 // non-zeros are few and scattered, as those of p are for thousands of pivots).
 // over_inverse: M is the transposed inverse; only its dense rows are read and every output takes
 // the single term of its unit row (k_rev_coltile<.., kUnit>).
+// price: the cost product also leaves one pricing partial per workgroup (h->sel_parts of them).
+// nz_counts: per-256 non-zero counts of coef, if a kernel already left them (chip-wide listing).
 int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, int64_t ncols, const double* coef,
-               const double* base, double* out, bool list_rows = false, bool over_inverse = false) {
+               const double* base, double* out, bool list_rows = false, bool over_inverse = false, bool price = false,
+               const int32_t* nz_counts = nullptr) {
+  h->sel_parts = 0;
   // LDS-tiled product: 64 outputs per workgroup once that fills the chip, 16 below.  Measured at
   // m=32768 n=65536 with a dense coefficient vector: 2.87 / 1.18 ms against 3.58 / 1.49 ms for one
   // lane per output (pricing / B^-1 column); at m=4096: 0.30 against 0.47 ms per pivot.
@@ -179,13 +204,21 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
     const int32_t* rows = nullptr;
     const int32_t* n_listed = nullptr;
     if (list_rows && h->list_rows) {
-      hipLaunchKernelGGL(k_rev_list_nonzero, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, coef, nrows, h->idx_rows, &h->st->n_rows);
+      if (nz_counts)
+        hipLaunchKernelGGL(k_rev_list_nonzero_wide, dim3((unsigned)((nrows + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
+                           h->st, coef, nrows, nz_counts, h->idx_rows, &h->st->n_rows);
+      else
+        hipLaunchKernelGGL(k_rev_list_nonzero, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, coef, nrows, h->idx_rows, &h->st->n_rows);
       LP_TRY(check_launch("k_rev_list_nonzero"));
       rows = h->idx_rows;
       n_listed = &h->st->n_rows;
     }
-#define LPAMD_REV_COLTILE(W, C, L) \
-  hipLaunchKernelGGL((k_rev_coltile<W, C, L>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out, rows, n_listed)
+    const bool parts = price && base && h->wide;
+    double* sel_v = parts ? h->sel_v : nullptr;
+    if (parts) h->sel_parts = (int32_t)tgrid.x;
+#define LPAMD_REV_COLTILE(W, C, L)                                                                                                       \
+  hipLaunchKernelGGL((k_rev_coltile<W, C, L>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out, rows, n_listed, \
+                     (const int64_t*)nullptr, (const uint8_t*)nullptr, sel_v, h->sel_i, (const uint8_t*)h->is_basic, h->sh.N)
 #define LPAMD_REV_COLTILE_L(W, C)                         \
   do {                                                    \
     if (rows) LPAMD_REV_COLTILE(W, C, true);              \
@@ -230,9 +263,10 @@ int rev_rowdot(lpamd_rev_engine* h) {
   LP_TRY(check_launch("k_rev_rowdot"));
   if (rows) {
     hipLaunchKernelGGL(k_rev_unit_rows_p, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
-                       h->BinvT, sh.ldb, sh.m, h->cB, h->pos, h->dense, h->pvec);
+                       h->BinvT, sh.ldb, sh.m, h->cB, h->pos, h->dense, h->pvec, h->wide ? h->cnt_p : nullptr);
     LP_TRY(check_launch("k_rev_unit_rows_p"));
   }
+  h->p_counted = rows && h->wide;
   return LPAMD_OK;
 }
 
@@ -283,10 +317,15 @@ int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
                        h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
     LP_TRY(check_launch("k_rev_select_leaving"));
     hipLaunchKernelGGL(k_rev_pivot_vectors, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
-                       h->st, sh, h->mu, h->xB, h->BinvT, h->scaled, h->touched, h->dense);
+                       h->st, sh, h->mu, h->xB, h->BinvT, h->scaled, h->touched, h->dense, h->cnt_touched, h->cnt_dense);
     LP_TRY(check_launch("k_rev_pivot_vectors"));
-    hipLaunchKernelGGL(k_rev_finish_pivot, one, sel, 0, h->stream, h->st, sh, h->mu, h->cB, h->obj, h->basis, h->is_basic, h->touched,
-                       h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
+    if (h->wide)
+      hipLaunchKernelGGL(k_rev_finish_pivot_wide, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
+                         h->st, sh, h->mu, h->cB, h->obj, h->basis, h->is_basic, h->touched, h->idx_upd, h->trace, h->trace_cap, h->dense,
+                         h->idx_dense, h->cnt_touched, h->cnt_dense);
+    else
+      hipLaunchKernelGGL(k_rev_finish_pivot, one, sel, 0, h->stream, h->st, sh, h->mu, h->cB, h->obj, h->basis, h->is_basic, h->touched,
+                         h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
     LP_TRY(check_launch("k_rev_finish_pivot"));
   }
   return rev_enqueue_update(h);
@@ -296,8 +335,18 @@ int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
 int rev_enqueue_iteration(lpamd_rev_engine* h, int64_t ncols_active) {
   const RevShape& sh = h->sh;
   LP_TRY(rev_rowdot(h));
-  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost, true));
-  LP_TRY(rev_enqueue_entering(h, false, ncols_active));
+  LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost, true, false, true,
+                    h->p_counted ? h->cnt_p : nullptr));
+  if (h->sel_parts > 0) {
+    // the cost product left pricing partials: fold them, then fetch the entering column chip-wide
+    hipLaunchKernelGGL(k_rev_select_entering_parts, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, h->sel_v, h->sel_i, h->sel_parts);
+    LP_TRY(check_launch("k_rev_select_entering_parts"));
+    hipLaunchKernelGGL(k_rev_gather_wide, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
+                       h->Trm, sh.ldw, sh.m, (int64_t)-1, h->colbuf);
+    LP_TRY(check_launch("k_rev_gather_wide"));
+  } else {
+    LP_TRY(rev_enqueue_entering(h, false, ncols_active));
+  }
   return rev_enqueue_pivot_tail(h, -1);
 }
 
@@ -462,6 +511,7 @@ int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_str
   if (const char* env = getenv("LPAMD_REV_UPDATE_UNROLL")) h->force_update_unroll = atoi(env);
   if (const char* env = getenv("LPAMD_REV_SPLIT")) h->force_split = atoi(env);
   if (const char* env = getenv("LPAMD_REV_TILE")) h->force_tile = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_WIDE")) h->wide = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_REV_LIST")) h->list_rows = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_REV_UNIT")) h->unit_rows = atoi(env) != 0;
   *out = h;

@@ -153,7 +153,9 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
     const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows_all, int64_t ncols,
     const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out,
     const int32_t* __restrict__ rows, const int32_t* __restrict__ n_listed,
-    const int64_t* __restrict__ rowof = nullptr, const uint8_t* __restrict__ dense = nullptr) {
+    const int64_t* __restrict__ rowof = nullptr, const uint8_t* __restrict__ dense = nullptr,
+    double* __restrict__ sel_v = nullptr, int64_t* __restrict__ sel_i = nullptr,
+    const uint8_t* __restrict__ is_basic = nullptr, int64_t rhs_col = -1) {
   constexpr int kH = 4096 / kW;                    // rows per chunk
   constexpr int kRowsPerPass = 2 * kRevThreads / kW;
   constexpr int kPasses = kH / kRowsPerPass;       // = 8
@@ -248,7 +250,20 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
   }
   if (kUnit && urow != INT32_MAX) acc = __dadd_rn(acc, uterm);   // the unit row sorts after every dense row
   const int64_t j = j0 + tid;
-  if (tid < kW && j < ncols) out[j] = kCost ? flushz(__dadd_rn(base[j], acc)) : acc;
+  double res = 0.0;
+  if (tid < kW && j < ncols) {
+    res = kCost ? flushz(__dadd_rn(base[j], acc)) : acc;
+    out[j] = res;
+  }
+  if (kCost && sel_v != nullptr && tid < kWave) {
+    // pricing partial of this workgroup's outputs (reference :240-252): most negative reduced cost
+    // among the non-basic columns, lowest column on ties; k_rev_select_entering_parts folds them
+    double bv = 0.0;
+    int64_t bi = -1;
+    if (tid < kW && j < ncols && j != rhs_col && !is_basic[j] && !((float)res > -1e-6f)) { bv = res; bi = j; }
+    wave_arg<false>(bv, bi);
+    if (tid == 0) { sel_v[blockIdx.x] = bv; sel_i[blockIdx.x] = bi; }
+  }
 }
 
 // out[r] = sum_i coef[i] * M[r * ld + i], i ascending: a dot product along every row
@@ -388,16 +403,86 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
   if (tid < kR && r0 + tid < nrows) out[row_at(r0 + tid)] = acc;
 }
 
+// Flagged elements of this 256-thread workgroup -> counts[blockIdx.x] (first half of the chip-wide
+// ordered compaction, see compact_flag_wide).
+__device__ __forceinline__ void count_flag_wide(bool flag, int32_t* __restrict__ counts, int* s_w /* [kRevThreads / kWave] */) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int n = __popcll(__ballot(flag));
+  if (lane == 0) s_w[wave] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+#pragma unroll
+    for (int w = 0; w < kRevThreads / kWave; w++) t += s_w[w];
+    counts[blockIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+// Second half: element i of this workgroup (one per thread, blocks of 256 in index order) is
+// appended to idx at its rank among all flagged elements; counts[] holds the per-workgroup
+// totals of an earlier kernel over the same flags.  The last workgroup writes the total.
+__device__ __forceinline__ void compact_flag_wide(bool flag, int64_t i, const int32_t* __restrict__ counts,
+                                                  int32_t* __restrict__ idx, int32_t* __restrict__ total_out,
+                                                  int* s_w /* [2 * kRevThreads / kWave] */) {
+  constexpr int kWaves = kRevThreads / kWave;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  int before = 0;
+  for (int b = threadIdx.x; b < (int)blockIdx.x; b += kRevThreads) before += counts[b];
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) before += __shfl_xor(before, off, kWave);
+  const unsigned long long mask = __ballot(flag);
+  if (lane == 0) { s_w[wave] = before; s_w[kWaves + wave] = __popcll(mask); }
+  __syncthreads();
+  int base = 0, here = 0;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) {
+    base += s_w[w];
+    if (w < wave) base += s_w[kWaves + w];
+    here += s_w[kWaves + w];
+  }
+  if (flag) idx[base + __popcll(mask & ((1ull << lane) - 1ull))] = (int32_t)i;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    int blocks_before = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; w++) blocks_before += s_w[w];
+    *total_out = blocks_before + here;
+  }
+  __syncthreads();   // s_w may be reused by the caller
+}
+
 // p[r] for the rows of the transposed inverse that are still unit rows: the sum over the row has one
-// term that can be non-zero, c_B[pos[r]] * BinvT[r][pos[r]], and starts from +0.0.
+// term that can be non-zero, c_B[pos[r]] * BinvT[r][pos[r]], and starts from +0.0.  With `counts` the
+// kernel also leaves, per 256 rows, how many entries of p are non-zero (dense rows were written by
+// k_rev_rowdot before), the first half of listing the rows the pricing product has to read.
 __global__ __launch_bounds__(kRevThreads) void k_rev_unit_rows_p(
     const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, const double* __restrict__ coef,
-    const int64_t* __restrict__ pos, const uint8_t* __restrict__ dense, double* __restrict__ out) {
+    const int64_t* __restrict__ pos, const uint8_t* __restrict__ dense, double* __restrict__ out, int32_t* __restrict__ counts) {
+  __shared__ int s_w[kRevThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const int64_t r = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
-  if (r >= nrows || dense[r]) return;
-  const int64_t i = pos[r];
-  out[r] = i >= 0 ? __dadd_rn(0.0, __dmul_rn(coef[i], M[r * ld + i])) : 0.0;
+  double v = 0.0;
+  if (r < nrows) {
+    if (dense[r]) {
+      v = out[r];
+    } else {
+      const int64_t i = pos[r];
+      v = i >= 0 ? __dadd_rn(0.0, __dmul_rn(coef[i], M[r * ld + i])) : 0.0;
+      out[r] = v;
+    }
+  }
+  if (counts) count_flag_wide(v != 0.0, counts, s_w);
+}
+
+// Ascending list of the indices i < n with v[i] != 0 over the whole chip, given the per-256 counts
+// (same job as k_rev_list_nonzero, which does it in one workgroup).
+__global__ __launch_bounds__(kRevThreads) void k_rev_list_nonzero_wide(
+    const RevState* __restrict__ st, const double* __restrict__ v, int64_t n, const int32_t* __restrict__ counts,
+    int32_t* __restrict__ idx, int32_t* __restrict__ count) {
+  __shared__ int s_w[2 * kRevThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const int64_t i = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
+  compact_flag_wide(i < n && v[i] != 0.0, i, counts, idx, count, s_w);
 }
 
 // colbuf[r] = M[r * ld + col] for rows r = threadIdx.x, threadIdx.x + blockDim.x, ...; the strided
@@ -472,6 +557,25 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering(
   const int64_t e = s_e;
   if (!kGather || e < 0) return;
   gather_column(Trm, sh.ldw, e, sh.m, colbuf);
+}
+
+// Pricing from the partials the cost product left (one per workgroup of k_rev_coltile): same
+// outcome as k_rev_select_entering<false, false> without a second pass over the costs.
+__global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering_parts(
+    RevState* __restrict__ st, const double* __restrict__ sel_v, const int64_t* __restrict__ sel_i, int n_parts) {
+  __shared__ double s_v[kRevSelectThreads / kWave];
+  __shared__ int64_t s_i[kRevSelectThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const bool limit = st->iter >= st->max_iter;
+  double bv = 0.0;
+  int64_t bi = -1;
+  for (int k = threadIdx.x; k < n_parts; k += kRevSelectThreads) take_min(bv, bi, sel_v[k], sel_i[k]);
+  block_arg<false, kRevSelectThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    if (limit) st->status = ST_LIMIT;
+    else if (bi < 0) st->status = ST_SOLVED;
+    else st->e = bi;
+  }
 }
 
 // out[r] = M[r * ld + col] with one row per lane over the whole grid; col < 0 reads the
@@ -645,20 +749,29 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
 // row of BinvT telling whether the update has to visit it.
 __global__ __launch_bounds__(kRevThreads) void k_rev_pivot_vectors(
     const RevState* __restrict__ st, RevShape sh, const double* __restrict__ mu, double* __restrict__ xB,
-    const double* __restrict__ BinvT, double* __restrict__ scaled, uint8_t* __restrict__ touched, uint8_t* __restrict__ dense) {
+    const double* __restrict__ BinvT, double* __restrict__ scaled, uint8_t* __restrict__ touched, uint8_t* __restrict__ dense,
+    int32_t* __restrict__ cnt_touched, int32_t* __restrict__ cnt_dense) {
+  __shared__ int s_w[kRevThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const int64_t k = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
-  if (k >= sh.m) return;
-  const int64_t l = st->leaving;
-  const double ratio = st->ratio;
-  const double s = -1.0 / mu[l];
-  const double old = BinvT[k * sh.ldb + l];
-  xB[k] = k == l ? ratio : __dadd_rn(xB[k], __dmul_rn(mu[k], ratio));
-  const double sc = __dmul_rn(old, s);
-  scaled[k] = sc;
-  const bool changes = old != 0.0 || sc != 0.0;   // the update makes this row dense
-  if (changes) dense[k] = 1;
-  touched[k] = (st->full_update != 0 || changes) ? 1 : 0;
+  bool visit = false, is_dense = false;
+  if (k < sh.m) {
+    const int64_t l = st->leaving;
+    const double ratio = st->ratio;
+    const double s = -1.0 / mu[l];
+    const double old = BinvT[k * sh.ldb + l];
+    xB[k] = k == l ? ratio : __dadd_rn(xB[k], __dmul_rn(mu[k], ratio));
+    const double sc = __dmul_rn(old, s);
+    scaled[k] = sc;
+    const bool changes = old != 0.0 || sc != 0.0;   // the update makes this row dense
+    is_dense = changes || dense[k] != 0;
+    if (changes) dense[k] = 1;
+    visit = st->full_update != 0 || changes;
+    touched[k] = visit ? 1 : 0;
+  }
+  // per-256-row totals for the ordered lists k_rev_finish_pivot_wide writes
+  count_flag_wide(visit, cnt_touched, s_w);
+  count_flag_wide(is_dense, cnt_dense, s_w);
 }
 
 // Closes the pivot after k_rev_pivot_vectors: list of the rows to update, mu[leaving] = 0,
@@ -673,6 +786,31 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_finish_pivot(
   list_flagged(touched, sh.m, idx_upd, s_w, &st->n_upd);
   list_flagged(dense, sh.m, idx_dense, s_w, &st->n_dense);
   if (threadIdx.x == 0) {
+    mu[l] = 0.0;
+    is_basic[e] = 1;
+    is_basic[basis[l]] = 0;
+    basis[l] = e;
+    cB[l] = obj[e];
+    if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = l; }
+    st->iter = it + 1;
+    st->full_update = 0;
+  }
+}
+
+// The same over the whole chip, one row per lane, with the per-256-row totals k_rev_pivot_vectors left.
+__global__ __launch_bounds__(kRevThreads) void k_rev_finish_pivot_wide(
+    RevState* __restrict__ st, RevShape sh, double* __restrict__ mu, double* __restrict__ cB, const double* __restrict__ obj,
+    int64_t* __restrict__ basis, uint8_t* __restrict__ is_basic, const uint8_t* __restrict__ touched, int32_t* __restrict__ idx_upd,
+    int64_t* __restrict__ trace, int64_t trace_cap, const uint8_t* __restrict__ dense, int32_t* __restrict__ idx_dense,
+    const int32_t* __restrict__ cnt_touched, const int32_t* __restrict__ cnt_dense) {
+  __shared__ int s_w[2 * kRevThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const int64_t k = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
+  const bool in = k < sh.m;
+  compact_flag_wide(in && touched[k] != 0, k, cnt_touched, idx_upd, &st->n_upd, s_w);
+  compact_flag_wide(in && dense[k] != 0, k, cnt_dense, idx_dense, &st->n_dense, s_w);
+  if (k == 0) {
+    const int64_t e = st->e, it = st->iter, l = st->leaving;
     mu[l] = 0.0;
     is_basic[e] = 1;
     is_basic[basis[l]] = 0;

@@ -76,6 +76,8 @@ def test_revised_synthetic_trace_and_inverse(lpamd, m, n, seed):
                                    {"LPAMD_REV_TILE": "0", "LPAMD_REV_COLSUM_VEC": "2"}, {"LPAMD_REV_SPLIT": "1"},
                                    {"LPAMD_REV_LIST": "0"}, {"LPAMD_REV_LIST": "0", "LPAMD_REV_TILE": "64"},
                                    {"LPAMD_REV_UNIT": "0"}, {"LPAMD_REV_UNIT": "0", "LPAMD_REV_ROWDOT_ROWS": "64"},
+                                   {"LPAMD_REV_WIDE": "0"}, {"LPAMD_REV_WIDE": "0", "LPAMD_REV_SPLIT": "1"},
+                                   {"LPAMD_REV_SPLIT": "1", "LPAMD_REV_TILE": "16"}, {"LPAMD_REV_SPLIT": "1", "LPAMD_REV_UNIT": "0"},
                                    {"LPAMD_REV_ROWDOT_ROWS": "64", "LPAMD_REV_UPDATE_UNROLL": "16", "LPAMD_REV_TILE": "64",
                                     "LPAMD_REV_SPLIT": "1"}])
 @pytest.mark.parametrize("m,n,seed", [(200, 333, 4), (65, 129, 5)])
