@@ -235,6 +235,11 @@ int lpamd_rev_optimum(lpamd_rev_engine* eng, double* out);
  * scattered by basis_indices, zero elsewhere (reference :259-263). */
 int lpamd_rev_column_values(lpamd_rev_engine* eng, double* x);
 int lpamd_rev_pivot_count(lpamd_rev_engine* eng, int64_t* n);
+/* Sizes of the exact-sparsity lists as of the last pivot of the last lpamd_rev_solve call (for
+ * traffic accounting; no reference counterpart): rows of the inverse its rank-1 update visited,
+ * rows of the tableau the pricing product read (non-zeros of c_B^T B^-1), rows of the inverse
+ * that are no longer unit rows.  Any pointer may be NULL. */
+int lpamd_rev_list_sizes(lpamd_rev_engine* eng, int64_t* n_update_rows, int64_t* n_pricing_rows, int64_t* n_dense_rows);
 /* (entering column, leaving basis position) of every pivot so far */
 int lpamd_rev_trace(lpamd_rev_engine* eng, int64_t* entering, int64_t* leaving_pos, int64_t cap, int64_t* n);
 /* Debug/test access; any pointer may be NULL.  Binv, BinvT: m x m row-major

@@ -247,19 +247,31 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
 // p = c_B^T * B^-1: a dot product along every row of the transposed inverse
 int rev_rowdot(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
-  // 16 rows per workgroup: the list of dense rows is short for thousands of pivots, and 16-row tiles put
-  // four times as many workgroups on it as 64-row tiles (m=32768 n=65536 after 3000 pivots: 0.66 against
-  // 0.90 ms per pivot; the first pivots do not care).  LPAMD_REV_ROWDOT_ROWS=64 keeps the wide variant.
-  const bool rows64 = h->force_rowdot_rows == 64;
-  const int kr = rows64 ? 64 : 16;
-  const dim3 grid((unsigned)((sh.m + kr - 1) / kr)), block(kRevThreads);
+  // Short list of dense rows (thousands of pivots pass before it grows beyond a few thousand): one
+  // wavefront per row, so that the chip is busy although the rows are few.  Long list: 16 rows per
+  // workgroup through LDS tiles, where 16 lanes add 16 rows side by side (64-row tiles lost against
+  // 16-row tiles at every list length measured).  Both kernels take any list length; the choice uses
+  // the length the host last saw, which only costs speed when it is stale.
+  // LPAMD_REV_ROWDOT_ROWS=1|16|64 pins the variant.
   const int32_t* rows = h->unit_rows ? h->idx_dense : nullptr;
   const int32_t* n_listed = h->unit_rows ? &h->st->n_dense : nullptr;
+  const int64_t n_hint = rows ? (int64_t)h->h_st.n_dense : sh.m;
+  const int kr = h->force_rowdot_rows ? h->force_rowdot_rows : (n_hint <= 4096 ? 1 : 16);
+  if (kr == 1) {
+    const dim3 grid((unsigned)((sh.m + 3) / 4)), block(kRevThreads);
+    if (rows)
+      hipLaunchKernelGGL((k_rev_rowdot_wave<true, 8>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed);
+    else
+      hipLaunchKernelGGL((k_rev_rowdot_wave<false, 8>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed);
+  } else {
+    const bool rows64 = kr == 64;
+    const dim3 grid((unsigned)((sh.m + (rows64 ? 64 : 16) - 1) / (rows64 ? 64 : 16))), block(kRevThreads);
 #define LPAMD_REV_ROWDOT(R, L) \
   hipLaunchKernelGGL((k_rev_rowdot<R, L>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed)
-  if (rows64) { if (rows) LPAMD_REV_ROWDOT(64, true); else LPAMD_REV_ROWDOT(64, false); }
-  else { if (rows) LPAMD_REV_ROWDOT(16, true); else LPAMD_REV_ROWDOT(16, false); }
+    if (rows64) { if (rows) LPAMD_REV_ROWDOT(64, true); else LPAMD_REV_ROWDOT(64, false); }
+    else { if (rows) LPAMD_REV_ROWDOT(16, true); else LPAMD_REV_ROWDOT(16, false); }
 #undef LPAMD_REV_ROWDOT
+  }
   LP_TRY(check_launch("k_rev_rowdot"));
   if (rows) {
     hipLaunchKernelGGL(k_rev_unit_rows_p, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
@@ -644,6 +656,14 @@ int lpamd_rev_column_values(lpamd_rev_engine* h, double* x) {
 int lpamd_rev_pivot_count(lpamd_rev_engine* h, int64_t* n) {
   CHECK_REV(h);
   *n = h->h_st.iter;
+  return LPAMD_OK;
+}
+
+int lpamd_rev_list_sizes(lpamd_rev_engine* h, int64_t* n_update_rows, int64_t* n_pricing_rows, int64_t* n_dense_rows) {
+  CHECK_REV(h);
+  if (n_update_rows) *n_update_rows = h->h_st.n_upd;
+  if (n_pricing_rows) *n_pricing_rows = h->h_st.n_rows;
+  if (n_dense_rows) *n_dense_rows = h->h_st.n_dense;
   return LPAMD_OK;
 }
 

@@ -93,6 +93,7 @@ def library():
         "lpamd_rev_column_values": (ctypes.c_int, [vp, vp]),
         "lpamd_rev_pivot_count": (ctypes.c_int, [vp, P(i64)]),
         "lpamd_rev_trace": (ctypes.c_int, [vp, vp, vp, i64, P(i64)]),
+        "lpamd_rev_list_sizes": (ctypes.c_int, [vp, P(i64), P(i64), P(i64)]),
         "lpamd_rev_read_state": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
@@ -375,6 +376,12 @@ class RevisedTableauEngine:
         got = ctypes.c_int64()
         _ck(self.L.lpamd_rev_trace(self.h, e.ctypes.data, l.ctypes.data, n, ctypes.byref(got)))
         return list(zip(e[:got.value].tolist(), l[:got.value].tolist()))
+
+    def list_sizes(self):
+        """(rows the last update visited, rows the last pricing product read, dense rows of the inverse)."""
+        a, b, c = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_rev_list_sizes(self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def read_state(self, inverse=True, transposed=True):
         """(Binv, BinvT, xB, cB, basis); a matrix that is not asked for comes back as None."""

@@ -2,9 +2,9 @@
 set -e
 timeout -k 10 400 python -u -m pytest tests/test_revised_gpu.py -x -q --timeout 150 --timeout-method thread > gpurun_out/rev_test.log 2>&1 || { tail -20 gpurun_out/rev_test.log; exit 1; }
 tail -2 gpurun_out/rev_test.log
-for W in 1 0; do
-  echo "WIDE=$W"
-  LPAMD_REV_WIDE=$W timeout -k 10 200 python scripts/revised_bench.py --m 32768 --n 65536 --pivots 40 --warmup 3
-  LPAMD_REV_WIDE=$W timeout -k 10 300 python scripts/revised_bench.py --m 32768 --n 65536 --pivots 200 --warmup 3000
-  LPAMD_REV_WIDE=$W timeout -k 10 300 python scripts/revised_bench.py --m 4096 --n 8192 --pivots 200 --warmup 20
+for R in 1 16; do
+  echo "ROWDOT_ROWS=$R"
+  LPAMD_REV_ROWDOT_ROWS=$R timeout -k 10 200 python scripts/revised_bench.py --m 32768 --n 65536 --pivots 40 --warmup 3
+  LPAMD_REV_ROWDOT_ROWS=$R timeout -k 10 300 python scripts/revised_bench.py --m 32768 --n 65536 --pivots 200 --warmup 3000
+  LPAMD_REV_ROWDOT_ROWS=$R timeout -k 10 300 python scripts/revised_bench.py --m 4096 --n 8192 --pivots 200 --warmup 20
 done

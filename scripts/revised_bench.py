@@ -37,7 +37,8 @@ def main():
     # B^-1 * column reads the inverse once; c_B^T * B^-1 and the rank-1 update only touch the parts
     # with non-zero multipliers (up to 8 m^2 and 16 m^2 more when the inverse has filled in)
     dense_bytes = 8.0 * (m * W + m * m)
-    print(json.dumps({"metric": "revised_simplex_pivots_per_second", "value": k / dt, "ms_per_pivot": 1e3 * dt / max(k, 1),
+    n_upd, n_rows, n_dense = eng.list_sizes()
+    print(json.dumps({"update_rows": n_upd, "pricing_rows": n_rows, "dense_rows": n_dense, "metric": "revised_simplex_pivots_per_second", "value": k / dt, "ms_per_pivot": 1e3 * dt / max(k, 1),
                       "pivots": k, "result": res, "m": a.m, "n": a.n, "dense_products_GB_per_pivot": dense_bytes / 1e9,
                       "dense_products_GBps": dense_bytes * k / dt / 1e9}))
     eng.close()

@@ -71,7 +71,8 @@ def test_revised_synthetic_trace_and_inverse(lpamd, m, n, seed):
     eng.close()
 
 
-@pytest.mark.parametrize("knobs", [{"LPAMD_REV_ROWDOT_ROWS": "64"}, {"LPAMD_REV_UPDATE_UNROLL": "16"},
+@pytest.mark.parametrize("knobs", [{"LPAMD_REV_ROWDOT_ROWS": "64"}, {"LPAMD_REV_ROWDOT_ROWS": "16"}, {"LPAMD_REV_ROWDOT_ROWS": "1"},
+                                   {"LPAMD_REV_ROWDOT_ROWS": "1", "LPAMD_REV_UNIT": "0"}, {"LPAMD_REV_UPDATE_UNROLL": "16"},
                                    {"LPAMD_REV_TILE": "64"}, {"LPAMD_REV_TILE": "16"}, {"LPAMD_REV_TILE": "0"},
                                    {"LPAMD_REV_TILE": "0", "LPAMD_REV_COLSUM_VEC": "2"}, {"LPAMD_REV_SPLIT": "1"},
                                    {"LPAMD_REV_LIST": "0"}, {"LPAMD_REV_LIST": "0", "LPAMD_REV_TILE": "64"},
