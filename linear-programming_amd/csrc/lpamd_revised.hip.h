@@ -248,7 +248,7 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
 int rev_rowdot(lpamd_rev_engine* h) {
   const RevShape& sh = h->sh;
   // Short list of dense rows (thousands of pivots pass before it grows beyond a few thousand): one
-  // wavefront per row, so that the chip is busy although the rows are few.  Long list: 16 rows per
+  // workgroup per row, so that the chip is busy although the rows are few.  Long list: 16 rows per
   // workgroup through LDS tiles, where 16 lanes add 16 rows side by side (64-row tiles lost against
   // 16-row tiles at every list length measured).  Both kernels take any list length; the choice uses
   // the length the host last saw, which only costs speed when it is stale.
@@ -258,11 +258,11 @@ int rev_rowdot(lpamd_rev_engine* h) {
   const int64_t n_hint = rows ? (int64_t)h->h_st.n_dense : sh.m;
   const int kr = h->force_rowdot_rows ? h->force_rowdot_rows : (n_hint <= 4096 ? 1 : 16);
   if (kr == 1) {
-    const dim3 grid((unsigned)((sh.m + 3) / 4)), block(kRevThreads);
+    const dim3 grid((unsigned)std::min<int64_t>(sh.m, 2048)), block(kRevThreads);   // rows are dealt round-robin
     if (rows)
-      hipLaunchKernelGGL((k_rev_rowdot_wave<true, 8>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed);
+      hipLaunchKernelGGL((k_rev_rowdot_row<true, 8>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed);
     else
-      hipLaunchKernelGGL((k_rev_rowdot_wave<false, 8>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed);
+      hipLaunchKernelGGL((k_rev_rowdot_row<false, 8>), grid, block, 0, h->stream, h->st, h->BinvT, sh.ldb, sh.m, sh.m, h->cB, h->pvec, rows, n_listed);
   } else {
     const bool rows64 = kr == 64;
     const dim3 grid((unsigned)((sh.m + (rows64 ? 64 : 16) - 1) / (rows64 ? 64 : 16))), block(kRevThreads);

@@ -403,55 +403,71 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_rowdot(
   if (tid < kR && r0 + tid < nrows) out[row_at(r0 + tid)] = acc;
 }
 
-// The same dot product with one wavefront per row, for a short list of dense rows (a few
-// thousand at most): the LDS-tiled kernel above puts 16 rows on a workgroup and leaves most of
-// the chip idle then.  The wavefront streams its row with coalesced 16-byte loads (kU per lane
-// in flight); the sum still runs in index order: for every 128-column piece the lanes whose
-// coefficients are non-zero are visited in ascending order (ballot + read-lane), and the
-// accumulator is kept redundantly in all lanes.
 __device__ __forceinline__ double read_lane_f64(double x, int src /* wave-uniform */) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), src);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
   return __hiloint2double(hi, lo);
 }
 
+// The same dot product with one workgroup per row, for a short list of dense rows (a few
+// thousand at most): the LDS-tiled kernel above puts 16 rows on a workgroup and leaves most of
+// the chip idle then.  The four wavefronts stream the row together, 2 * 64 * kU columns each per
+// round, with coalesced 16-byte loads; each leaves the products of its non-zero coefficients in
+// LDS, compacted in column order, and the first wavefront adds the four lists one after the
+// other, so the sum still runs in index order (64 products per LDS read, handed from lane to
+// lane with read-lane; the accumulator lives redundantly in all its lanes).
 template <bool kListed, int kU>
-__global__ __launch_bounds__(kRevThreads) void k_rev_rowdot_wave(
+__global__ __launch_bounds__(kRevThreads) void k_rev_rowdot_row(
     const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows_all, int64_t ncols,
     const double* __restrict__ coef, double* __restrict__ out, const int32_t* __restrict__ rows,
     const int32_t* __restrict__ n_listed) {
+  constexpr int kWaves = kRevThreads / kWave;
+  constexpr int kCols = 2 * kWave * kU;            // columns of one wavefront per round
+  __shared__ double s_prod[kWaves][kCols];
+  __shared__ int s_n[kWaves];
   if (st->status != ST_RUNNING) return;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const unsigned long long below = (1ull << lane) - 1ull;
   const int64_t nrows = kListed ? (int64_t)*n_listed : nrows_all;
-  const int64_t pos = (int64_t)blockIdx.x * (kRevThreads / kWave) + wave;
-  if (pos >= nrows) return;
-  const int64_t r = kListed ? (int64_t)rows[pos] : pos;
-  const double* __restrict__ row = M + r * ld;
-  double acc = 0.0;
-  for (int64_t base = 0; base < ncols; base += 2 * kWave * kU) {
-    double2 v[kU], c[kU];
+  for (int64_t pos = blockIdx.x; pos < nrows; pos += gridDim.x) {
+    const int64_t r = kListed ? (int64_t)rows[pos] : pos;
+    const double* __restrict__ row = M + r * ld;
+    double acc = 0.0;
+    for (int64_t base = 0; base < ncols; base += (int64_t)kWaves * kCols) {
+      double2 v[kU], c[kU];
 #pragma unroll
-    for (int u = 0; u < kU; u++) {
-      const int64_t col = base + (int64_t)u * 2 * kWave + 2 * lane;   // ld is even and covers ncols rounded up
-      const bool in = col < ld;
-      v[u] = in ? *reinterpret_cast<const double2*>(row + col) : make_double2(0.0, 0.0);
-      c[u].x = col < ncols ? coef[col] : 0.0;
-      c[u].y = col + 1 < ncols ? coef[col + 1] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < kU; u++) {
-      const double px = __dmul_rn(c[u].x, v[u].x), py = __dmul_rn(c[u].y, v[u].y);
-      const unsigned long long mx = __ballot(c[u].x != 0.0), my = __ballot(c[u].y != 0.0);
-      unsigned long long todo = mx | my;
-      while (todo) {
-        const int src = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        if ((mx >> src) & 1) acc = __dadd_rn(acc, read_lane_f64(px, src));
-        if ((my >> src) & 1) acc = __dadd_rn(acc, read_lane_f64(py, src));
+      for (int u = 0; u < kU; u++) {
+        const int64_t col = base + (int64_t)wave * kCols + (int64_t)u * 2 * kWave + 2 * lane;   // ld is even and covers ncols rounded up
+        v[u] = col < ld ? *reinterpret_cast<const double2*>(row + col) : make_double2(0.0, 0.0);
+        c[u].x = col < ncols ? coef[col] : 0.0;
+        c[u].y = col + 1 < ncols ? coef[col + 1] : 0.0;
       }
+      int n = 0;
+#pragma unroll
+      for (int u = 0; u < kU; u++) {
+        const bool nx = c[u].x != 0.0, ny = c[u].y != 0.0;
+        const unsigned long long mx = __ballot(nx), my = __ballot(ny);
+        const int at = n + __popcll(mx & below) + __popcll(my & below);
+        if (nx) s_prod[wave][at] = __dmul_rn(c[u].x, v[u].x);
+        if (ny) s_prod[wave][at + (nx ? 1 : 0)] = __dmul_rn(c[u].y, v[u].y);
+        n += __popcll(mx) + __popcll(my);
+      }
+      if (lane == 0) s_n[wave] = n;
+      __syncthreads();
+      if (wave == 0) {
+        for (int w = 0; w < kWaves; w++) {
+          const int cnt = s_n[w];
+          for (int k0 = 0; k0 < cnt; k0 += kWave) {
+            const double p = k0 + lane < cnt ? s_prod[w][k0 + lane] : 0.0;
+            const int lim = cnt - k0 < kWave ? cnt - k0 : kWave;
+            for (int t = 0; t < lim; t++) acc = __dadd_rn(acc, read_lane_f64(p, t));
+          }
+        }
+      }
+      __syncthreads();   // the lists are free again
     }
+    if (threadIdx.x == 0) out[r] = acc;
   }
-  if (lane == 0) out[r] = acc;
 }
 
 // Flagged elements of this 256-thread workgroup -> counts[blockIdx.x] (first half of the chip-wide
