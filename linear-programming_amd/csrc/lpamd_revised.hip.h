@@ -54,7 +54,8 @@ struct lpamd_rev_engine {
   // chip-wide kernels of their own (default: by size)
   // LPAMD_REV_TILE=0|16|64: column products one lane per output / through LDS tiles 16 or 64 outputs wide
   // LPAMD_REV_LIST=0: no row list in the pricing product (64-row chunk skipping only)
-  int force_vec = 0, force_rowdot_rows = 0, force_update_unroll = 0, force_split = -1, force_tile = -1;
+  int force_vec = 0, force_rowdot_rows = 0, force_update_unroll = 0, force_split = -1, force_tile = -1, force_colsum_threads = 0;
+  int price_tile = -1;   // LPAMD_REV_PRICE_TILE: tile width of the pricing product alone (0 = one lane per output)
   bool list_rows = true;
   // LPAMD_REV_UNIT=0: the products over the inverse read every row instead of the dense rows only
   bool unit_rows = true;
@@ -188,7 +189,14 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
   // LDS-tiled product: 64 outputs per workgroup once that fills the chip, 16 below.  Measured at
   // m=32768 n=65536 with a dense coefficient vector: 2.87 / 1.18 ms against 3.58 / 1.49 ms for one
   // lane per output (pricing / B^-1 column); at m=4096: 0.30 against 0.47 ms per pivot.
-  const int tile = h->force_tile >= 0 ? h->force_tile : (ncols >= 64 * 256 ? 64 : 16);
+  int tile = h->force_tile >= 0 ? h->force_tile : (ncols >= 64 * 256 ? 64 : 16);
+  // The pricing product over a short row list (the non-zeros of p stay few for thousands of pivots)
+  // streams best with one lane per output: whole rows go by in 2 KB runs per workgroup, and the few
+  // terms per output need no LDS staging.  Measured at m=32768 n=65536 with 665 listed rows: 80 us
+  // (6.5 TB/s) against 146 us tiled.  The choice uses the list length the host last saw.
+  bool listed_lanes = false;
+  if (price && list_rows && h->list_rows && h->force_tile < 0 && ncols >= 64 * 256 && h->h_st.n_rows <= 8192) { tile = 0; listed_lanes = true; }
+  if (price && h->price_tile >= 0) { tile = h->price_tile; listed_lanes = false; }
   if (tile == 64 || tile == 16) {
     const dim3 tgrid((unsigned)((ncols + tile - 1) / tile)), tblock(kRevThreads);
     if (over_inverse && h->unit_rows && !base) {
@@ -232,14 +240,38 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
   }
   // one lane per output: two columns (16 bytes) per lane once that still leaves a wavefront per CU,
   // one wavefront per workgroup on narrow outputs so that the lanes spread over all CUs
-  const bool vec2 = h->force_vec ? h->force_vec == 2 : ncols >= 2 * 64 * 128;
-  const int threads = ncols / (vec2 ? 2 : 1) >= 512 * kRevThreads ? kRevThreads : kWave;
+  const int32_t* rows = nullptr;
+  const int32_t* n_listed = nullptr;
+  if (list_rows && h->list_rows && !over_inverse) {
+    if (nz_counts)
+      hipLaunchKernelGGL(k_rev_list_nonzero_wide, dim3((unsigned)((nrows + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
+                         h->st, coef, nrows, nz_counts, h->idx_rows, &h->st->n_rows);
+    else
+      hipLaunchKernelGGL(k_rev_list_nonzero, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, coef, nrows, h->idx_rows, &h->st->n_rows);
+    LP_TRY(check_launch("k_rev_list_nonzero"));
+    rows = h->idx_rows;
+    n_listed = &h->st->n_rows;
+  }
+  const bool vec2 = h->force_vec ? h->force_vec == 2 : (ncols >= 2 * 64 * 128 && !listed_lanes);
+  int threads = ncols / (vec2 ? 2 : 1) >= 512 * kRevThreads ? kRevThreads : kWave;
+  if (listed_lanes) threads = kRevThreads;
+  if (h->force_colsum_threads) threads = h->force_colsum_threads;
   const int64_t per_block = (int64_t)threads * (vec2 ? 2 : 1);
   const dim3 grid((unsigned)((ncols + per_block - 1) / per_block)), block(threads);
-#define LPAMD_REV_COLSUM(V, C) \
-  hipLaunchKernelGGL((k_rev_colsum<V, 16, C>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out)
-  if (base) { if (vec2) LPAMD_REV_COLSUM(2, true); else LPAMD_REV_COLSUM(1, true); }
-  else { if (vec2) LPAMD_REV_COLSUM(2, false); else LPAMD_REV_COLSUM(1, false); }
+  const bool parts = price && base && h->wide;
+  double* sel_v = parts ? h->sel_v : nullptr;
+  if (parts) h->sel_parts = (int32_t)grid.x;
+#define LPAMD_REV_COLSUM(V, C, L)                                                                                                             \
+  hipLaunchKernelGGL((k_rev_colsum<V, 16, C, L>), grid, block, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out, rows, n_listed, \
+                     sel_v, h->sel_i, (const uint8_t*)h->is_basic, h->sh.N)
+#define LPAMD_REV_COLSUM_L(V, C)                 \
+  do {                                           \
+    if (rows) LPAMD_REV_COLSUM(V, C, true);      \
+    else LPAMD_REV_COLSUM(V, C, false);          \
+  } while (0)
+  if (base) { if (vec2) LPAMD_REV_COLSUM_L(2, true); else LPAMD_REV_COLSUM_L(1, true); }
+  else { if (vec2) LPAMD_REV_COLSUM_L(2, false); else LPAMD_REV_COLSUM_L(1, false); }
+#undef LPAMD_REV_COLSUM_L
 #undef LPAMD_REV_COLSUM
   return check_launch("k_rev_colsum");
 }
@@ -524,6 +556,8 @@ int lpamd_rev_create(lpamd_rev_engine** out, int64_t m, int64_t N, void* hip_str
   if (const char* env = getenv("LPAMD_REV_SPLIT")) h->force_split = atoi(env);
   if (const char* env = getenv("LPAMD_REV_TILE")) h->force_tile = atoi(env);
   if (const char* env = getenv("LPAMD_REV_WIDE")) h->wide = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_REV_PRICE_TILE")) h->price_tile = atoi(env);
+  if (const char* env = getenv("LPAMD_REV_COLSUM_THREADS")) h->force_colsum_threads = atoi(env);
   if (const char* env = getenv("LPAMD_REV_LIST")) h->list_rows = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_REV_UNIT")) h->unit_rows = atoi(env) != 0;
   *out = h;

@@ -91,50 +91,83 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* s_w /* [kRevSele
 // row loads in flight; ld is even and covers the rounded-up column count, padding
 // entries are finite.  This is the plain form of the product; the engine runs the
 // LDS-tiled k_rev_coltile by default (LPAMD_REV_TILE=0 selects this one).
-template <int kVec, int kUnroll, bool kCost>
+template <int kVec, int kUnroll, bool kCost, bool kListed = false>
 __global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
-    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows, int64_t ncols,
-    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out) {
+    const RevState* __restrict__ st, const double* __restrict__ M, int64_t ld, int64_t nrows_all, int64_t ncols,
+    const double* __restrict__ coef, const double* __restrict__ base, double* __restrict__ out,
+    const int32_t* __restrict__ rows = nullptr, const int32_t* __restrict__ n_listed = nullptr,
+    double* __restrict__ sel_v = nullptr, int64_t* __restrict__ sel_i = nullptr,
+    const uint8_t* __restrict__ is_basic = nullptr, int64_t rhs_col = -1) {
+  __shared__ double s_v[kRevThreads / kWave];
+  __shared__ int64_t s_i[kRevThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const int64_t j = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * kVec;   // 64..256 lanes per workgroup
-  if (j >= ncols) return;
-  const double* __restrict__ p = M + j;
+  const bool pricing = kCost && sel_v != nullptr;   // then every lane stays for the workgroup's arg-min
+  if (j >= ncols && !pricing) return;
+  const double* __restrict__ p = M + (j < ncols ? j : 0);
+  const int64_t nrows = j < ncols ? (kListed ? (int64_t)*n_listed : nrows_all) : 0;   // positions in the ascending row list, or rows
+  auto row_at = [&](int64_t pos) -> int64_t { return kListed ? (int64_t)rows[pos] : pos; };
   double a0 = 0.0, a1 = 0.0;
   int64_t r = 0;
   for (; r + kUnroll <= nrows; r += kUnroll) {
+    int64_t rr[kUnroll];
+#pragma unroll
+    for (int u = 0; u < kUnroll; u++) rr[u] = row_at(r + u);
     if constexpr (kVec == 2) {
       double2 v[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
-        const double* q = p + (r + u) * ld;
+        const double* q = p + rr[u] * ld;
         v[u].x = __builtin_nontemporal_load(q);
         v[u].y = __builtin_nontemporal_load(q + 1);
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) {
-        const double c = coef[r + u];
+        const double c = coef[rr[u]];
         a0 = __dadd_rn(a0, __dmul_rn(c, v[u].x));
         a1 = __dadd_rn(a1, __dmul_rn(c, v[u].y));
       }
     } else {
       double v[kUnroll];
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) v[u] = __builtin_nontemporal_load(p + (r + u) * ld);
+      for (int u = 0; u < kUnroll; u++) v[u] = __builtin_nontemporal_load(p + rr[u] * ld);
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) a0 = __dadd_rn(a0, __dmul_rn(coef[r + u], v[u]));
+      for (int u = 0; u < kUnroll; u++) a0 = __dadd_rn(a0, __dmul_rn(coef[rr[u]], v[u]));
     }
   }
   for (; r < nrows; r++) {
-    const double c = coef[r];
-    a0 = __dadd_rn(a0, __dmul_rn(c, p[r * ld]));
-    if constexpr (kVec == 2) a1 = __dadd_rn(a1, __dmul_rn(c, p[r * ld + 1]));
+    const int64_t row = row_at(r);
+    const double c = coef[row];
+    a0 = __dadd_rn(a0, __dmul_rn(c, p[row * ld]));
+    if constexpr (kVec == 2) a1 = __dadd_rn(a1, __dmul_rn(c, p[row * ld + 1]));
+  }
+  if (j < ncols) {
+    if constexpr (kCost) {
+      a0 = flushz(__dadd_rn(base[j], a0));
+      if (kVec == 2 && j + 1 < ncols) a1 = flushz(__dadd_rn(base[j + 1], a1));
+    }
+    out[j] = a0;
+    if (kVec == 2 && j + 1 < ncols) out[j + 1] = a1;
   }
   if constexpr (kCost) {
-    a0 = flushz(__dadd_rn(base[j], a0));
-    if (kVec == 2 && j + 1 < ncols) a1 = flushz(__dadd_rn(base[j + 1], a1));
+    if (pricing) {
+      // pricing partial of this workgroup's outputs (reference :240-252): most negative reduced cost
+      // among the non-basic columns, lowest column on ties; k_rev_select_entering_parts folds them
+      double bv = 0.0;
+      int64_t bi = -1;
+      if (j < ncols && j != rhs_col && !is_basic[j] && !((float)a0 > -1e-6f)) { bv = a0; bi = j; }
+      if (kVec == 2 && j + 1 < ncols && j + 1 != rhs_col && !is_basic[j + 1] && !((float)a1 > -1e-6f)) take_min(bv, bi, a1, j + 1);
+      wave_arg<false>(bv, bi);
+      const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, n_waves = blockDim.x / kWave;
+      if (lane == 0) { s_v[wave] = bv; s_i[wave] = bi; }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        for (int w = 1; w < n_waves; w++) take_min(bv, bi, s_v[w], s_i[w]);
+        sel_v[blockIdx.x] = bv;
+        sel_i[blockIdx.x] = bi;
+      }
+    }
   }
-  out[j] = a0;
-  if (kVec == 2 && j + 1 < ncols) out[j + 1] = a1;
 }
 
 // The same sum as k_rev_colsum, out[j] = sum_r coef[r] * M[r * ld + j] (+ base and zero drop with
