@@ -7,6 +7,7 @@
 // tools/mps_load.py does.
 #include <algorithm>
 #include <cctype>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 
@@ -45,7 +46,11 @@ int main(int argc, char** argv) {
   LPModel::PivotingStrategy strategy = LPModel::MAX_COST;
   if (argc >= 4) strategy = ParsePivotingStrategy(argv[3]);
   bool print_trace = false;
-  for (int i = 4; i < argc; i++) print_trace |= std::string(argv[i]) == "--trace";
+  bool print_time = false;   // --time: wall time of the solve call and its pivot count on stderr (stdout stays the reference's)
+  for (int i = 4; i < argc; i++) {
+    print_trace |= std::string(argv[i]) == "--trace";
+    print_time |= std::string(argv[i]) == "--time";
+  }
 
   Parser parser;
   Model model = {{}, OptimizationObject(FLOAT)};
@@ -74,16 +79,21 @@ int main(int argc, char** argv) {
   Result result = ERROR;
   Num optimum;
   std::map<Variable, Num> solution;
+  std::chrono::steady_clock::time_point t0, t1;
   if (revised) {   // reference solver.cc:135-145
     lp_model.ToTableau(COLUMN_ONLY);
+    t0 = std::chrono::steady_clock::now();
     result = lp_model.TableauRevisedSimplexSolve();
+    t1 = std::chrono::steady_clock::now();
     if (result == SOLVED) {
       optimum = lp_model.GetTableauRevisedSimplexOptimum();
       solution = lp_model.GetTableauRevisedSimplexSolution();
     }
   } else {         // reference solver.cc:123-133
     lp_model.ToTableau();
+    t0 = std::chrono::steady_clock::now();
     result = lp_model.TableauSimplexSolve();
+    t1 = std::chrono::steady_clock::now();
     if (result == SOLVED) {
       optimum = lp_model.GetTableauSimplexOptimum();
       solution = lp_model.GetTableauSimplexSolution();
@@ -99,6 +109,9 @@ int main(int argc, char** argv) {
   } else {
     std::cout << "Error\n";
   }
+  if (print_time)
+    std::cerr << "solve_ms " << std::chrono::duration<double, std::milli>(t1 - t0).count() << " pivots "
+              << lp_model.TableauPivotTrace().size() << "\n";
   if (print_trace)
     for (auto& p : lp_model.TableauPivotTrace()) std::cerr << "pivot " << p.first << " " << p.second << "\n";
   return 0;
