@@ -9,8 +9,9 @@ resident in HBM before the timed region starts.
 
 N == 1 runs the device-resident loop of the C ABI (lpamd_run_pivots); N > 1 is
 launched by torch.distributed.run with one rank per GPU and runs the
-column-sharded loop (RCCL all-gather of candidates + broadcast of the pivot
-column).  Rank 0 prints ONE JSON line.
+column-sharded loop (RCCL all-gather of candidates + integer sum-all-reduce of
+the pivot column, both on a second stream beside the rank-1 update for
+max_cost).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import importlib
@@ -103,6 +104,8 @@ def main():
     ap.add_argument("--strategy", default="max_cost", choices=["max_cost", "max_reduction"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", default=os.environ.get("LPAMD_EXCHANGE", "lookahead"), choices=["lookahead", "allreduce", "broadcast"],
+                    help="N > 1: how the shards exchange the entering column (see linear-programming_amd/sharded.py)")
     args = ap.parse_args()
 
     import torch
@@ -149,7 +152,7 @@ def main():
         shard = sharded.EngineShard(m, N, rank, world, dev)
         shard.eng.fill_synthetic(n, args.seed)
         eng = shard.eng
-        solver = sharded.ShardedSolver(shard)
+        solver = sharded.ShardedSolver(shard, exchange=args.exchange)
         run = lambda k: solver.run_pivots(strat, k)
 
     res, done = run(W)
@@ -192,7 +195,8 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": args.config, "m": m, "n": n, "stored_columns": N + 1, "strategy": args.strategy,
-                   "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world},
+                   "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world,
+                   "exchange": (args.exchange if (world > 1 or force_sharded) else "none (device-resident loop)")},
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

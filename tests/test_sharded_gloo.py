@@ -58,7 +58,14 @@ def _worker(rank, world, port, case, strategy_name, out_dir, exchange):
     (("synthetic", 33, 64, 3), "max_reduction", "broadcast"),
 ])
 def test_two_rank_loop_matches_oracle(tmp_path, case, strategy, exchange):
-    world = 2
+    _check_loop(tmp_path, case, strategy, exchange, 2)
+
+
+def test_four_rank_lookahead_loop_matches_oracle(tmp_path):
+    _check_loop(tmp_path, ("synthetic", 37, 70, 5), "max_cost", "lookahead", 4)
+
+
+def _check_loop(tmp_path, case, strategy, exchange, world):
     mp.spawn(_worker, args=(world, _free_port(), case, strategy, str(tmp_path), exchange), nprocs=world, join=True)
     _, m, n, seed = case
     dt = lo.DenseTableau.synthetic(m, n, seed)
@@ -74,7 +81,8 @@ def test_two_rank_loop_matches_oracle(tmp_path, case, strategy, exchange):
         obj[r["gcols"]] = r["obj"]
     T[:, dt.N] = ranks[0]["rhs"]
     obj[dt.N] = float(ranks[0]["obj_const"])
-    assert np.array_equal(ranks[0]["rhs"].view(np.uint64), ranks[1]["rhs"].view(np.uint64))
+    for r in ranks[1:]:
+        assert np.array_equal(ranks[0]["rhs"].view(np.uint64), r["rhs"].view(np.uint64))
     assert np.array_equal(T.view(np.uint64), dt.T.view(np.uint64))
     assert np.array_equal(obj.view(np.uint64), dt.obj.view(np.uint64))
 
