@@ -73,3 +73,19 @@ def test_solver_cli_revised_texts_for_unbounded_and_infeasible(tmp_path):
     p.write_text("max x1\nst\nx1 <= 1\nx1 >= 2\nx1 >= 0\n")
     out = subprocess.run([os.path.join(BIN, "solver"), str(p), "revised_simplex_tableau"], capture_output=True, text=True)
     assert out.stdout == "No Solution\n"
+
+
+@pytest.mark.parametrize("name", ["agg", "agg2", "agg3"])
+def test_solver_cli_revised_objective_on_goldens_outside_the_reference_ctest(name):
+    """Revised-simplex outputs the reference ships but does not test (reference CMakeLists.txt:138):
+    the objective agrees within 1e-9 relative, the pivot sequence is the oracle's."""
+    out = subprocess.run([os.path.join(BIN, "solver"), _path(name), "revised_simplex_tableau", "max_cost", "--trace"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    want = open(os.path.join(GOLDEN, "netlib_sol_revised_extra", name + ".txt")).read()
+    got_obj, want_obj = float(out.stdout.split("\n")[0]), float(want.split("\n")[0])
+    assert abs(got_obj - want_obj) <= 1e-9 * abs(want_obj)
+    text, rt = lo.solve_text_revised(case_text(name))
+    assert out.stdout.rstrip("\n") == text.rstrip("\n")
+    got = [tuple(map(int, l.split()[1:])) for l in out.stderr.splitlines() if l.startswith("pivot ")]
+    assert got == rt.trace()

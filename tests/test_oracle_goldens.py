@@ -104,3 +104,16 @@ from cases import REVISED_CASES, revised_golden
 def test_revised_oracle_reproduces_reference_golden(name, golden):
     out, rt = lo.solve_text_revised(case_text(name))
     assert out.rstrip("\n") == revised_golden(golden).rstrip("\n")
+
+
+@pytest.mark.parametrize("name", ["agg", "agg2", "agg3"])
+def test_oracle_revised_objective_on_goldens_outside_the_reference_ctest(name):
+    """The reference ships revised-simplex outputs for agg, agg2 and agg3 but its ctest skips them
+    ("takes too long", reference CMakeLists.txt:138).  They were not produced by the pivot sequence
+    the tested goldens pin (a handful of variables sit at another optimal vertex), so only the
+    objective is compared, at the 1e-9 relative tolerance the path promises."""
+    out, rt = lo.solve_text_revised(case_text(name))
+    want = open(os.path.join(GOLDEN, "netlib_sol_revised_extra", name + ".txt")).read()
+    got_obj, want_obj = float(out.split("\n")[0]), float(want.split("\n")[0])
+    assert abs(got_obj - want_obj) <= 1e-9 * abs(want_obj)
+    assert [l.split(" = ")[0] for l in out.strip().split("\n")[1:]] == [l.split(" = ")[0] for l in want.strip().split("\n")[1:]]
