@@ -62,6 +62,11 @@ struct lpamd_engine {
   bool update_prec = true;      // load col' together with the tableau batch
   bool update_prec_fused = true;
   bool fuse_pr_enabled = true;  // max-reduction pricing of the next iteration inside the update
+  // Two-launch MAX_COST loop (k_pivot_setup_small + k_update) on one GPU while columns are short
+  bool two_launch = false;
+  int price_buf = 0;            // which half of part_v/part_i holds the fresh pricing partials (two-launch loop)
+  int update_slot = -1;         // counter slot handed to the next k_update launch (-1: three-launch loop)
+  int64_t slot_counter = 0;
   int device = 0;
   hipStream_t stream = nullptr;
   bool own_stream = false;
@@ -302,7 +307,7 @@ void launch_update(lpamd_engine* e, int grid, bool nt, bool fuse_pr) {
 #define LPAMD_LAUNCH_UPDATE(NT, PC, PR)                                                                                         \
   hipLaunchKernelGGL((k_update<kUnroll, NT, PC, PR>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, \
                      e->rowp, e->active, e->st, e->sh, e->is_basic, e->basis, e->rhs_next, e->cand_next, e->cmin, e->crow,      \
-                     e->pr_stamp)
+                     e->pr_stamp, e->update_slot)
   if (fuse_pr) {   // max-reduction pricing of the next iteration rides along
     if (nt && e->update_prec_fused) LPAMD_LAUNCH_UPDATE(true, true, true);
     else if (nt) LPAMD_LAUNCH_UPDATE(true, false, true);
@@ -389,6 +394,23 @@ int enqueue_pivot(lpamd_engine* e, bool find_row, Candidate* cand, const double*
 // One iteration of the main loop on one GPU: 4 launches for MAX_COST (pricing
 // partials, ratio partials, set-up + row gather, update), 4 for MAX_REDUCTION.
 int enqueue_iteration(lpamd_engine* e, int strategy) {
+  if (strategy == LPAMD_MAX_COST && e->two_launch) {
+    // pricing fold + ratio test + set-up in one kernel (partials read from one half of the buffers, the
+    // next ones written to the other), then the update with this pivot's counter slot
+    if (!e->price_partials_fresh) { LP_TRY(enqueue_price_partial(e)); e->price_buf = 0; }
+    const int cur = e->price_buf, nxt = 1 - cur, slot = (int)(e->slot_counter++ & 1);
+    const int grid = e->n_row_blocks + e->n_price_part;
+    hipLaunchKernelGGL(k_pivot_setup_small, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->part_v + cur * kMaxPartials,
+                       e->part_i + cur * kMaxPartials, e->n_price_part, e->n_row_blocks, e->st, slot, e->colp, e->obj, e->is_basic, e->basis,
+                       e->rowp, e->active, e->trace, e->trace_cap, e->part_v + nxt * kMaxPartials, e->part_i + nxt * kMaxPartials, e->rhs_next,
+                       e->cand_next);
+    LP_TRY(check_launch("k_pivot_setup_small"));
+    e->price_buf = nxt;
+    e->update_slot = slot;
+    const int rc = enqueue_update(e, false);
+    e->update_slot = -1;
+    return rc;
+  }
   if (strategy == LPAMD_MAX_COST) {
     // the previous pivot's set-up kernel already left the pricing partials of this iteration
     if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
@@ -404,7 +426,15 @@ int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   LP_TRY(pull_state(e));
   e->h_st.status = ST_RUNNING;
   e->h_st.max_iter = budget < 0 ? std::numeric_limits<int64_t>::max() : e->h_st.iter + budget;
+  e->h_st.n_active = e->h_st.n_active2 = 0;   // both counter slots of the two-launch loop start empty
   LP_TRY(push_state(e));
+  e->slot_counter = 0;
+  struct RestorePriceBuf {   // every other path keeps the pricing partials in the first half
+    lpamd_engine* e;
+    ~RestorePriceBuf() {
+      if (e->price_buf != 0) { e->price_buf = 0; e->price_partials_fresh = false; }
+    }
+  } restore{e};
   // With a budget the whole run is enqueued at once (kernels turn into no-ops
   // once the status leaves RUNNING); without one the batch grows geometrically.
   int64_t batch = budget >= 0 ? 1024 : 8;
@@ -516,6 +546,11 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_UPDATE_PREC_FUSED")) e->update_prec_fused = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_FUSE_PR")) e->fuse_pr_enabled = atoi(env) != 0;
   if (const char* env = getenv("LPAMD_UPDATE_GRID")) e->update_grid = std::max(1, atoi(env));
+  // Measured: the ratio test inside every set-up workgroup beats a third launch on the reference's own
+  // inputs (m up to ~1000: israel 14.7 -> 12.6 ms, fit1d 45 -> 41 ms per solve) and loses at m = 4096
+  // (9460 against 9780 pivots/s), so it is taken up to 2048 rows
+  e->two_launch = world == 1 && m <= 2048;
+  if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
   } else {

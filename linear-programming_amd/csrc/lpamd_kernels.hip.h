@@ -49,7 +49,7 @@ struct PivotState {  // device resident, one per engine
   int64_t e, r, d;   // global ids of entering / leaving column and the pivot row
   double a, ce, f, g;
   int32_t n_active;  // local columns whose pivot-row entry is non-zero
-  int32_t pad1;
+  int32_t n_active2; // second counter of the two-launch loop (the counters alternate from pivot to pivot)
 };
 
 // The tableau shard: local column l lives in half[l & 1] at column slot l >> 1.
@@ -366,28 +366,16 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
 // the list of columns the update has to touch (row' != 0), and the pricing partial
 // of the NEXT iteration on the updated objective row (so the main loop needs no
 // separate pricing launch).  The first column workgroup records the pivot.
-template <bool kFindRow>
-__global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
-    Tab T, Shape sh, const Candidate* __restrict__ cand, const double* __restrict__ xcol,
-    const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
-    int64_t d_override, PivotState* __restrict__ st, double* __restrict__ colp,
-    double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
-    double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
-    double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
-    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next) {
-  __shared__ double s_v[kPartialThreads / kWave];
-  __shared__ int64_t s_i[kPartialThreads / kWave];
-  if (st->status != ST_RUNNING) return;
-  const Candidate c = *cand;
-  if (c.gcol < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_SOLVED; return; }   // no entering column
-  int64_t r;
-  if (kFindRow) {
-    double best;
-    fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r, s_v, s_i);
-  } else {
-    r = c.row;
-  }
-  if (r < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
+// Everything of the set-up once the candidate c and the row r are known (see k_pivot_finalize).
+// n_active_ctr: the counter the active list is appended under; bump_iter: the pivot count is
+// advanced here (otherwise the update kernel does it, see k_pivot_setup_small).
+__device__ __forceinline__ void pivot_setup_body(
+    const Tab& T, const Shape& sh, const Candidate& c, int64_t r, const double* __restrict__ xcol, int n_row_blocks,
+    int64_t d_override, PivotState* __restrict__ st, int32_t* __restrict__ n_active_ctr, bool bump_iter,
+    double* __restrict__ colp, double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
+    const int64_t* __restrict__ basis, double* __restrict__ rowp, int32_t* __restrict__ active,
+    int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, double* s_v, int64_t* s_i) {
   const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
   const double* __restrict__ col = xcol ? xcol : T.col(eo / sh.world);
   const double a = col[r];
@@ -437,7 +425,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
       const int lane = threadIdx.x & (kWave - 1);
       const int leader = __ffsll((long long)mask) - 1;
       int base = 0;
-      if (lane == leader) base = atomicAdd(&st->n_active, __popcll(mask));
+      if (lane == leader) base = atomicAdd(n_active_ctr, __popcll(mask));
       base = __shfl(base, leader, kWave);
       if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
     }
@@ -453,8 +441,84 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
     st->a = a; st->ce = c.ce; st->f = f; st->g = g;
     const int64_t it = st->iter;
     if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = r; }
-    st->iter = it + 1;
+    if (bump_iter) st->iter = it + 1;
   }
+}
+
+template <bool kFindRow>
+__global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
+    Tab T, Shape sh, const Candidate* __restrict__ cand, const double* __restrict__ xcol,
+    const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
+    int64_t d_override, PivotState* __restrict__ st, double* __restrict__ colp,
+    double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
+    double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
+    double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const Candidate c = *cand;
+  if (c.gcol < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_SOLVED; return; }   // no entering column
+  int64_t r;
+  if (kFindRow) {
+    double best;
+    fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r, s_v, s_i);
+  } else {
+    r = c.row;
+  }
+  if (r < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
+  pivot_setup_body(T, sh, c, r, xcol, n_row_blocks, d_override, st, &st->n_active, true, colp, obj, is_basic, basis, rowp, active,
+                   trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, s_v, s_i);
+}
+
+// Two-launch MAX_COST iteration for short columns on one GPU (where a pivot is bound by launches,
+// not by HBM): pricing fold, ratio test and set-up in ONE kernel, then k_update.  Every workgroup
+// folds the pricing partials the previous set-up left and runs the whole ratio test itself (2 * 8 * m
+// bytes from L2 and m / 256 divisions per lane, cheaper than a kernel boundary while m is a few
+// thousand), so all workgroups know (e, r) without a grid-wide exchange.  What the three-launch loop
+// settles at kernel boundaries is kept apart differently here:
+//  - the pricing partials are read from one buffer and those of the next iteration written to the
+//    other (the host swaps them per iteration);
+//  - the active-column counters alternate (slot), k_update clears the one it does not read;
+//  - the pivot count is advanced by k_update, so that every workgroup of this launch sees the
+//    same count in the budget test.
+__global__ __launch_bounds__(kPartialThreads) void k_pivot_setup_small(
+    Tab T, Shape sh, const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part, int n_row_blocks,
+    PivotState* __restrict__ st, int slot, double* __restrict__ colp,
+    double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
+    double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
+    double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (st->iter >= st->max_iter) { if (lead) st->status = ST_LIMIT; return; }
+  double ce;
+  int64_t l;
+  fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);   // reference lp_simplex_tableau.cc:188-198
+  if (l < 0) { if (lead) st->status = ST_SOLVED; return; }
+  Candidate c;
+  c.key = ce; c.gcol = gcol_of(l * sh.world + sh.rank, sh.N); c.row = -1; c.ce = ce;
+  // ratio test (reference lp_simplex_tableau.cc:207-227), the whole column in every workgroup
+  const double* __restrict__ col = T.col(l);
+  const double* __restrict__ rhs = T.col(sh.nloc);
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < sh.m; i += kPartialThreads) {
+    const double a = col[i];
+    if ((float)a > -1e-6f) continue;   // skips _IsZero and _IsNonNegative entries alike
+    const double ratio = rhs[i] / (-a);
+    if (bv > ratio) { bv = ratio; bi = i; }
+  }
+  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) s_i[0] = bi;
+  __syncthreads();
+  const int64_t r = s_i[0];
+  __syncthreads();
+  if (r < 0) { if (lead) st->status = ST_UNBOUNDED; return; }
+  pivot_setup_body(T, sh, c, r, nullptr, n_row_blocks, -1, st, slot ? &st->n_active2 : &st->n_active, false, colp, obj, is_basic, basis,
+                   rowp, active, trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, s_v, s_i);
 }
 
 // ------------------------------------------------------------ rank-1 update
@@ -500,11 +564,20 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
     const double* __restrict__ rowp, const int32_t* __restrict__ active,
     const PivotState* __restrict__ st, Shape sh, uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis,
     const double* __restrict__ rhs_next, const uint8_t* __restrict__ cand_next,
-    double* __restrict__ cmin, int64_t* __restrict__ crow, int64_t* __restrict__ pr_stamp) {
+    double* __restrict__ cmin, int64_t* __restrict__ crow, int64_t* __restrict__ pr_stamp, int slot) {
+  // slot < 0: three-launch loop (one counter, the set-up kernel advances the pivot count);
+  // slot 0 / 1: two-launch loop (k_pivot_setup_small): read counter `slot`, clear the other one and
+  // advance the pivot count here
   __shared__ double s_v[kUpdateThreads / kWave];
   __shared__ int64_t s_i[kUpdateThreads / kWave];
   if (st->status != ST_RUNNING) return;
+  const int n_active = slot == 1 ? st->n_active2 : st->n_active;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (slot >= 0) {
+      PivotState* wst = const_cast<PivotState*>(st);   // nothing in this launch reads these fields again
+      if (slot == 1) wst->n_active = 0; else wst->n_active2 = 0;
+      wst->iter = st->iter + 1;
+    }
     // bookkeeping of reference lp_simplex_tableau.cc:16-28 for the pivot set up by k_pivot_finalize
     const int64_t e = st->e, d = st->d, eo = ordinal_of(e, sh.N);
     if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
@@ -514,7 +587,6 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
     }
     basis[st->r] = e;
   }
-  const int n_active = st->n_active;
   const int n_vec = (int)(lda / 2);                  // 16-byte vectors per column, a multiple of 256
   const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
   const double2* __restrict__ bn = reinterpret_cast<const double2*>(rhs_next);
