@@ -36,6 +36,7 @@ struct lpamd_rev_engine {
   double* sel_v = nullptr;      // pricing partials of the cost product, one per workgroup
   int64_t* sel_i = nullptr;
   int32_t sel_parts = 0;        // partials the last cost product left (0: none)
+  int32_t rt_parts = 0;         // ratio-test partials the last B^-1 * column product left (0: none)
   bool p_counted = false;       // cnt_p describes pvec
   RevState* st = nullptr;
   int64_t* trace = nullptr;
@@ -186,6 +187,7 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
                const double* base, double* out, bool list_rows = false, bool over_inverse = false, bool price = false,
                const int32_t* nz_counts = nullptr) {
   h->sel_parts = 0;
+  h->rt_parts = 0;
   // LDS-tiled product: 64 outputs per workgroup once that fills the chip, 16 below.  Measured at
   // m=32768 n=65536 with a dense coefficient vector: 2.87 / 1.18 ms against 3.58 / 1.49 ms for one
   // lane per output (pricing / B^-1 column); at m=4096: 0.30 against 0.47 ms per pivot.
@@ -201,12 +203,16 @@ int rev_colsum(lpamd_rev_engine* h, const double* M, int64_t ld, int64_t nrows, 
     const dim3 tgrid((unsigned)((ncols + tile - 1) / tile)), tblock(kRevThreads);
     if (over_inverse && h->unit_rows && !base) {
       const int32_t* n_dense = &h->st->n_dense;
+      // mu = B^-1 * column: with the basic solution at hand the workgroups also leave ratio-test partials
+      double* rt_v = h->wide ? h->sel_v : nullptr;
+      const double* xb = rt_v ? h->xB : nullptr;
+      if (rt_v) h->rt_parts = (int32_t)tgrid.x;
       if (tile == 64)
-        hipLaunchKernelGGL((k_rev_coltile<64, false, true, true>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out,
-                           h->idx_dense, n_dense, h->rows, h->dense);
+        hipLaunchKernelGGL((k_rev_coltile<64, false, true, true>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, xb, out,
+                           h->idx_dense, n_dense, h->rows, h->dense, rt_v, h->sel_i);
       else
-        hipLaunchKernelGGL((k_rev_coltile<16, false, true, true>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, base, out,
-                           h->idx_dense, n_dense, h->rows, h->dense);
+        hipLaunchKernelGGL((k_rev_coltile<16, false, true, true>), tgrid, tblock, 0, h->stream, h->st, M, ld, nrows, ncols, coef, xb, out,
+                           h->idx_dense, n_dense, h->rows, h->dense, rt_v, h->sel_i);
       return check_launch("k_rev_coltile");
     }
     const int32_t* rows = nullptr;
@@ -354,11 +360,13 @@ int rev_enqueue_pivot_tail(lpamd_rev_engine* h, int64_t forced_leaving) {
   LP_TRY(rev_colsum(h, h->BinvT, sh.ldb, sh.m, sh.m, h->colbuf, nullptr, h->mu, false, true));
   if (!h->split()) {
     hipLaunchKernelGGL((k_rev_select_leaving<true>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
-                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
+                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense,
+                       h->sel_v, h->sel_i, (int)h->rt_parts);
     LP_TRY(check_launch("k_rev_select_leaving"));
   } else {
     hipLaunchKernelGGL((k_rev_select_leaving<false>), one, sel, 0, h->stream, h->st, sh, forced_leaving, h->mu, h->xB, h->cB, h->obj,
-                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense);
+                       h->basis, h->is_basic, h->BinvT, h->scaled, h->idx_upd, h->trace, h->trace_cap, h->dense, h->idx_dense,
+                       h->sel_v, h->sel_i, (int)h->rt_parts);
     LP_TRY(check_launch("k_rev_select_leaving"));
     hipLaunchKernelGGL(k_rev_pivot_vectors, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
                        h->st, sh, h->mu, h->xB, h->BinvT, h->scaled, h->touched, h->dense, h->cnt_touched, h->cnt_dense);

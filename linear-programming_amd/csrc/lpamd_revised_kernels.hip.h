@@ -297,6 +297,19 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
     wave_arg<false>(bv, bi);
     if (tid == 0) { sel_v[blockIdx.x] = bv; sel_i[blockIdx.x] = bi; }
   }
+  if (!kCost && sel_v != nullptr && tid < kWave) {
+    // The product is mu = B^-1 * column and `base` carries the basic solution: ratio-test partial of
+    // this workgroup's positions (reference :282-297), smallest -x_B / mu over mu <= -1e-6f, lowest
+    // position on ties; k_rev_select_leaving folds the partials instead of scanning mu again.
+    double bv = 0.0;
+    int64_t bi = -1;
+    if (tid < kW && j < ncols && is_neg(res)) {
+      const double ratio = -(base[j] / res);
+      if (ratio < DBL_MAX) { bv = ratio; bi = j; }
+    }
+    wave_arg<false>(bv, bi);
+    if (tid == 0) { sel_v[blockIdx.x] = bv; sel_i[blockIdx.x] = bi; }
+  }
 }
 
 // out[r] = sum_i coef[i] * M[r * ld + i], i ascending: a dot product along every row
@@ -748,7 +761,8 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
     RevState* __restrict__ st, RevShape sh, int64_t forced_leaving, double* __restrict__ mu, double* __restrict__ xB,
     double* __restrict__ cB, const double* __restrict__ obj, int64_t* __restrict__ basis, uint8_t* __restrict__ is_basic,
     const double* __restrict__ BinvT, double* __restrict__ scaled, int32_t* __restrict__ idx_upd, int64_t* __restrict__ trace,
-    int64_t trace_cap, uint8_t* __restrict__ dense, int32_t* __restrict__ idx_dense) {
+    int64_t trace_cap, uint8_t* __restrict__ dense, int32_t* __restrict__ idx_dense,
+    const double* __restrict__ part_v = nullptr, const int64_t* __restrict__ part_i = nullptr, int n_parts = 0) {
   __shared__ double s_v[kRevSelectThreads / kWave];
   __shared__ int64_t s_i[kRevSelectThreads / kWave];
   __shared__ int s_w[kRevSelectThreads / kWave + 1];
@@ -759,7 +773,10 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_leaving(
   const bool full = st->full_update != 0;
   double bv = 0.0;
   int64_t bi = -1;
-  if (forced_leaving < 0) {
+  if (forced_leaving < 0 && n_parts > 0) {   // the B^-1 * column product left ratio-test partials
+    for (int k = threadIdx.x; k < n_parts; k += kRevSelectThreads) take_min(bv, bi, part_v[k], part_i[k]);
+    block_arg<false, kRevSelectThreads>(bv, bi, s_v, s_i);
+  } else if (forced_leaving < 0) {
     for (int64_t ib = threadIdx.x; ib < sh.m; ib += 8 * kRevSelectThreads) {
       double mi[8], xi[8];
 #pragma unroll
