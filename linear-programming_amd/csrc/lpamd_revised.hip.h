@@ -390,12 +390,10 @@ int rev_enqueue_iteration(lpamd_rev_engine* h, int64_t ncols_active) {
   LP_TRY(rev_colsum(h, h->Trm, sh.ldw, sh.m, ncols_active, h->pvec, h->obj, h->cost, true, false, true,
                     h->p_counted ? h->cnt_p : nullptr));
   if (h->sel_parts > 0) {
-    // the cost product left pricing partials: fold them, then fetch the entering column chip-wide
-    hipLaunchKernelGGL(k_rev_select_entering_parts, dim3(1), dim3(kRevSelectThreads), 0, h->stream, h->st, h->sel_v, h->sel_i, h->sel_parts);
-    LP_TRY(check_launch("k_rev_select_entering_parts"));
-    hipLaunchKernelGGL(k_rev_gather_wide, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream, h->st,
-                       h->Trm, sh.ldw, sh.m, (int64_t)-1, h->colbuf);
-    LP_TRY(check_launch("k_rev_gather_wide"));
+    // the cost product left pricing partials: fold them and fetch the entering column chip-wide
+    hipLaunchKernelGGL(k_rev_enter_and_gather, dim3((unsigned)((sh.m + kRevThreads - 1) / kRevThreads)), dim3(kRevThreads), 0, h->stream,
+                       h->st, h->sel_v, h->sel_i, (int)h->sel_parts, h->Trm, sh.ldw, sh.m, h->colbuf);
+    LP_TRY(check_launch("k_rev_enter_and_gather"));
   } else {
     LP_TRY(rev_enqueue_entering(h, false, ncols_active));
   }

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_colsum(
   if constexpr (kCost) {
     if (pricing) {
       // pricing partial of this workgroup's outputs (reference :240-252): most negative reduced cost
-      // among the non-basic columns, lowest column on ties; k_rev_select_entering_parts folds them
+      // among the non-basic columns, lowest column on ties; k_rev_enter_and_gather folds them
       double bv = 0.0;
       int64_t bi = -1;
       if (j < ncols && j != rhs_col && !is_basic[j] && !((float)a0 > -1e-6f)) { bv = a0; bi = j; }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kRevThreads) void k_rev_coltile(
   }
   if (kCost && sel_v != nullptr && tid < kWave) {
     // pricing partial of this workgroup's outputs (reference :240-252): most negative reduced cost
-    // among the non-basic columns, lowest column on ties; k_rev_select_entering_parts folds them
+    // among the non-basic columns, lowest column on ties; k_rev_enter_and_gather folds them
     double bv = 0.0;
     int64_t bi = -1;
     if (tid < kW && j < ncols && j != rhs_col && !is_basic[j] && !((float)res > -1e-6f)) { bv = res; bi = j; }
@@ -672,23 +672,29 @@ __global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering(
   gather_column(Trm, sh.ldw, e, sh.m, colbuf);
 }
 
-// Pricing from the partials the cost product left (one per workgroup of k_rev_coltile): same
-// outcome as k_rev_select_entering<false, false> without a second pass over the costs.
-__global__ __launch_bounds__(kRevSelectThreads) void k_rev_select_entering_parts(
-    RevState* __restrict__ st, const double* __restrict__ sel_v, const int64_t* __restrict__ sel_i, int n_parts) {
-  __shared__ double s_v[kRevSelectThreads / kWave];
-  __shared__ int64_t s_i[kRevSelectThreads / kWave];
+// Pricing from the partials the cost product left (one per workgroup), same outcome as
+// k_rev_select_entering<false, false> without a second pass over the costs, and the chip-wide fetch
+// of the entering column, in one launch: every workgroup folds the partials itself (a few hundred
+// values from L2), so all of them know the entering column without a kernel boundary; the first
+// one records the outcome.
+__global__ __launch_bounds__(kRevThreads) void k_rev_enter_and_gather(
+    RevState* __restrict__ st, const double* __restrict__ sel_v, const int64_t* __restrict__ sel_i, int n_parts,
+    const double* __restrict__ M, int64_t ld, int64_t nrows, double* __restrict__ out) {
+  __shared__ double s_v[kRevThreads / kWave];
+  __shared__ int64_t s_i[kRevThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const bool limit = st->iter >= st->max_iter;
-  double bv = 0.0;
-  int64_t bi = -1;
-  for (int k = threadIdx.x; k < n_parts; k += kRevSelectThreads) take_min(bv, bi, sel_v[k], sel_i[k]);
-  block_arg<false, kRevSelectThreads>(bv, bi, s_v, s_i);
-  if (threadIdx.x == 0) {
+  double bv;
+  int64_t bi;
+  fold_partials<false, kRevThreads>(sel_v, sel_i, n_parts, bv, bi, s_v, s_i);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     if (limit) st->status = ST_LIMIT;
     else if (bi < 0) st->status = ST_SOLVED;
     else st->e = bi;
   }
+  if (limit || bi < 0) return;
+  const int64_t r = (int64_t)blockIdx.x * kRevThreads + threadIdx.x;
+  if (r < nrows) out[r] = M[r * ld + bi];
 }
 
 // out[r] = M[r * ld + col] with one row per lane over the whole grid; col < 0 reads the
