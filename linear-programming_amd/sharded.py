@@ -255,29 +255,34 @@ class ShardedSolver:
     def _lookahead_exchange(self):
         """Exchange for the NEXT pivot: gather the records, keep the winner, deliver its column.
         With two streams it is ordered after what the loop stream holds so far (the export of
-        the local candidate) and runs beside what the loop stream gets next (the update)."""
+        the local candidate) and runs beside what the loop stream gets next (the update); the
+        caller has made the exchange stream torch's current stream."""
         sh = self.shard
-        if self.ev_sent is None:
-            self._gather_candidates()
-            sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
-            if self.use_dist:
-                self.comm.all_reduce_sum_words(self.xbuf_words)
-            return
-        self.ev_sent.record(sh.stream)
-        sh.xstream.wait_event(self.ev_sent)
-        with torch.cuda.stream(sh.xstream):
-            self._gather_candidates()
-            sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
-            if self.use_dist:
-                self.comm.all_reduce_sum_words(self.xbuf_words)
+        two_streams = self.ev_sent is not None
+        if two_streams:
+            self.ev_sent.record(sh.stream)
+            sh.xstream.wait_event(self.ev_sent)
+        self._gather_candidates()
+        sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
+        if self.use_dist:
+            self.comm.all_reduce_sum_words(self.xbuf_words)
+        if two_streams:
             self.ev_arrived.record(sh.xstream)
 
     def _run_lookahead(self, strategy, k):
         assert strategy == _eng.MAX_COST
         sh = self.shard
+        if self.ev_sent is None:
+            return self._lookahead_loop(k, False)
+        # The engine enqueues on its own stream whatever torch's current stream is, so the exchange
+        # stream stays current for the whole loop: the collectives and the fold land on it.
+        with torch.cuda.stream(sh.xstream):
+            return self._lookahead_loop(k, True)
+
+    def _lookahead_loop(self, k, two_streams):
+        sh = self.shard
         start = sh.pivot_count()
         sh.set_pivot_budget(k)
-        two_streams = self.ev_sent is not None
         sh.lookahead_export(self.cand, self.xlocal)      # nothing pending: the column as stored
         self._lookahead_exchange()
         enqueued = 0

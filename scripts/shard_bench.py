@@ -40,15 +40,16 @@ torch.cuda.synchronize()
 def exchange_ahead():
     ev_sent.record(shard.stream)
     shard.xstream.wait_event(ev_sent)
-    with torch.cuda.stream(shard.xstream):
-        dist.all_gather_into_tensor(one, cand)
-        cands[:4].copy_(one)
-        shard.lookahead_select(cands, xlocal, xbuf)
-        dist.all_reduce(xbuf.view(torch.int64))
-        ev_arrived.record(shard.xstream)
+    dist.all_gather_into_tensor(one, cand)
+    cands[:4].copy_(one)
+    shard.lookahead_select(cands, xlocal, xbuf)
+    dist.all_reduce(xbuf_words)
+    ev_arrived.record(shard.xstream)
+
+xbuf_words = xbuf.view(torch.int64)
 
 def run_lookahead(k):
-    with torch.cuda.stream(shard.stream):
+    with torch.cuda.stream(shard.xstream):   # the engine uses its own stream whatever torch's current one is
         shard.set_pivot_budget(k)
         shard.lookahead_export(cand, xlocal)
         exchange_ahead()
