@@ -321,6 +321,7 @@ void launch_update(lpamd_engine* e, int grid, bool nt, bool fuse_pr) {
 }
 
 int enqueue_update(lpamd_engine* e, bool fuse_pr) {
+  if (fuse_pr && e->update_slot >= 0) return set_err(LPAMD_E_STATE, "the two-launch loop has no fused max-reduction pricing");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->ev_used + 2 > e->ev.size()) {
@@ -486,6 +487,12 @@ int single_gpu_only(const lpamd_engine* e, const char* what) {
     CHECK_ENGINE(e);                                                           \
     if (!(e)->loaded) return set_err(LPAMD_E_STATE, "no tableau uploaded yet"); \
   } while (0)
+// entry points that change the tableau or start a pivot: not between lpamd_lookahead_setup and lpamd_lookahead_update
+#define CHECK_NO_PENDING_UPDATE(e)                                                                                   \
+  do {                                                                                                               \
+    if ((e)->update_pending)                                                                                         \
+      return set_err(LPAMD_E_STATE, "a pivot set up by lpamd_lookahead_setup still waits for lpamd_lookahead_update"); \
+  } while (0)
 
 }  // namespace
 
@@ -605,6 +612,7 @@ int lpamd_destroy(lpamd_engine* e) {
 
 int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic) {
   CHECK_ENGINE(e);
+  CHECK_NO_PENDING_UPDATE(e);
   const Shape& sh = e->sh;
   if (!T || !obj || !is_basic || ld < sh.m) return set_err(LPAMD_E_ARG, "upload: null buffer or ld < m");
   std::vector<double> hT[2], hobj(e->ncl, 0.0);
@@ -640,6 +648,7 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
 
 int lpamd_fill_synthetic(lpamd_engine* e, int64_t n_struct, uint64_t seed) {
   CHECK_ENGINE(e);
+  CHECK_NO_PENDING_UPDATE(e);
   const Shape& sh = e->sh;
   if (n_struct <= 0 || n_struct + sh.m != sh.N)
     return set_err(LPAMD_E_ARG, "synthetic LP needs N == n_struct + m (N=%lld n=%lld m=%lld)", (long long)sh.N, (long long)n_struct, (long long)sh.m);
@@ -697,6 +706,7 @@ int lpamd_read_row(const lpamd_engine* e, int64_t row, double* out) {
 
 int lpamd_write_objective(lpamd_engine* e, const double* obj) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   e->price_partials_fresh = false;
   if (!obj) return set_err(LPAMD_E_ARG, "write_objective: null");
   std::vector<double> h(e->ncl);
@@ -782,6 +792,7 @@ int lpamd_ratio_test(lpamd_engine* e, int64_t col, int64_t* r, int64_t* d) {
 
 int lpamd_pivot(lpamd_engine* e, int64_t d, int64_t col, int64_t r) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   LP_TRY(single_gpu_only(e, "lpamd_pivot"));
   const Shape& sh = e->sh;
   if (col < 0 || col > sh.N + 1 || col == sh.N || r < 0 || r >= sh.m || d > sh.N + 1)
@@ -797,6 +808,7 @@ int lpamd_pivot(lpamd_engine* e, int64_t d, int64_t col, int64_t r) {
 
 int lpamd_pivot_shard(lpamd_engine* e, int64_t d, int64_t col, int64_t r, double ce, const void* xbuf_dev) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   const Shape& sh = e->sh;
   if (col < 0 || col > sh.N + 1 || col == sh.N || r < 0 || r >= sh.m || d > sh.N + 1)
     return set_err(LPAMD_E_ARG, "pivot_shard: bad arguments d=%lld e=%lld r=%lld", (long long)d, (long long)col, (long long)r);
@@ -812,6 +824,7 @@ int lpamd_pivot_shard(lpamd_engine* e, int64_t d, int64_t col, int64_t r, double
 
 int lpamd_fill_column(lpamd_engine* e, int64_t col, double value) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   if (col < 0 || col > e->sh.N + 1) return set_err(LPAMD_E_ARG, "fill_column: bad column %lld", (long long)col);
   e->price_partials_fresh = false;
   LP_TRY(invalidate_pr(e));
@@ -834,6 +847,7 @@ int lpamd_set_basic_flag(lpamd_engine* e, int64_t col, int32_t flag) {
 
 int lpamd_run_pivots(lpamd_engine* e, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   LP_TRY(single_gpu_only(e, "lpamd_run_pivots"));
   if (!result) return set_err(LPAMD_E_ARG, "run_pivots: null result");
   LP_TRY(pull_state(e));
@@ -848,6 +862,7 @@ int lpamd_run_pivots(lpamd_engine* e, int32_t strategy, int64_t k, int32_t* resu
 // them read single rows / columns back.
 int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   LP_TRY(single_gpu_only(e, "lpamd_phase1"));
   if (!result) return set_err(LPAMD_E_ARG, "phase1: null result");
   const Shape& sh = e->sh;
@@ -940,6 +955,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
 
 int lpamd_solve(lpamd_engine* e, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   LP_TRY(single_gpu_only(e, "lpamd_solve"));
   if (!result) return set_err(LPAMD_E_ARG, "solve: null result");
   if (strategy != LPAMD_MAX_COST && strategy != LPAMD_MAX_REDUCTION)
@@ -1125,6 +1141,7 @@ int lpamd_export_column(lpamd_engine* e, int64_t col, void* xbuf_dev) {
 
 int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r, const void* xbuf_dev) {
   CHECK_LOADED(e);
+  CHECK_NO_PENDING_UPDATE(e);
   (void)col;
   (void)r;
   if (!xbuf_dev) return set_err(LPAMD_E_ARG, "apply_pivot: null exchange buffer");

@@ -383,3 +383,38 @@ def test_lookahead_exchange_overlaps_update_bit_exact(lpamd, world):
     T[:, N] = Tref[:, N]
     obj[N] = oref[N]
     assert np.array_equal(bits(T), bits(Tref)) and np.array_equal(bits(obj), bits(oref))
+
+
+def test_lookahead_calls_are_paired(lpamd):
+    """Between lpamd_lookahead_setup and lpamd_lookahead_update nothing else may start a pivot."""
+    eng = importlib.import_module("linear-programming_amd.engine")
+    dev = torch.device("cuda", 0)
+    m, n = 64, 100
+    e = lpamd.TableauEngine(m, n + m)
+    e.fill_synthetic(n, 3)
+    cand = torch.zeros(4, dtype=torch.float64, device=dev)
+    cands = torch.zeros(4, dtype=torch.float64, device=dev)
+    xlocal = torch.zeros(e.exchange_doubles(), dtype=torch.float64, device=dev)
+    xbuf = torch.zeros(e.exchange_doubles(), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    with pytest.raises(lpamd.LpamdError, match="no pivot has been set up"):
+        e.lookahead_update()
+    e.set_pivot_budget(1)
+    e.lookahead_export(cand.data_ptr(), xlocal.data_ptr())
+    torch.cuda.synchronize()
+    cands.copy_(cand)
+    e.lookahead_select(cands.data_ptr(), xlocal.data_ptr(), xbuf.data_ptr())
+    torch.cuda.synchronize()
+    e.lookahead_setup(xbuf.data_ptr())
+    with pytest.raises(lpamd.LpamdError, match="still waits"):
+        e.run_pivots(eng.MAX_COST, 1)
+    with pytest.raises(lpamd.LpamdError, match="still waits"):
+        e.lookahead_setup(xbuf.data_ptr())
+    e.lookahead_update()
+    assert e.poll() == eng.LIMIT and e.pivot_count() == 1
+    ref = lpamd.TableauEngine(m, n + m)
+    ref.fill_synthetic(n, 3)
+    ref.run_pivots(eng.MAX_COST, 1)
+    assert e.trace() == ref.trace()
+    a, b = e.download(), ref.download()
+    assert np.array_equal(bits(a[0]), bits(b[0])) and np.array_equal(bits(a[1]), bits(b[1]))
