@@ -66,6 +66,14 @@ struct lpamd_engine {
   bool two_launch = false;
   int price_buf = 0;            // which half of part_v/part_i holds the fresh pricing partials (two-launch loop)
   int update_slot = -1;         // counter slot handed to the next k_update launch (-1: three-launch loop)
+  // Two pivots per pass over the tableau (MAX_COST on one GPU, columns too long for the two-launch loop)
+  bool pair_mode = false;
+  bool last_loop_paired = false;
+  PairInfo* pair = nullptr;
+  double* colv = nullptr;       // entering column of the second pivot as the first one's update will leave it
+  double* colp2 = nullptr;      // col' and row' of the second pivot, list of columns either pivot touches
+  double* rowp2 = nullptr;
+  int32_t* active2 = nullptr;
   int64_t slot_counter = 0;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -386,6 +394,53 @@ int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* can
   return enqueue_update(e, fuse_pr && e->fuse_pr_enabled);
 }
 
+template <int kUnroll>
+void launch_update_pair(lpamd_engine* e, int grid, bool nt) {
+  if (nt)
+    hipLaunchKernelGGL((k_update_pair<kUnroll, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
+                       e->active, e->colp2, e->rowp2, e->active2, e->st, e->pair, e->sh, e->is_basic, e->basis);
+  else
+    hipLaunchKernelGGL((k_update_pair<kUnroll, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
+                       e->active, e->colp2, e->rowp2, e->active2, e->st, e->pair, e->sh, e->is_basic, e->basis);
+}
+
+// Second pivot of a pass (pricing fold + virtual column + ratio partials, set-up) and the pass itself,
+// for the pivot that k_pivot_finalize has just set up.
+int enqueue_pair_tail(lpamd_engine* e) {
+  double* rv = e->part_v + kMaxPartials;
+  int64_t* ri = e->part_i + kMaxPartials;
+  hipLaunchKernelGGL(k_pair_ratio, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->pair, e->part_v,
+                     e->part_i, e->n_price_part, e->colp, e->rowp, e->rhs_next, e->colv, rv, ri);
+  LP_TRY(check_launch("k_pair_ratio"));
+  hipLaunchKernelGGL(k_pair_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
+                     e->pair, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->colv, e->colp2, e->rowp2, e->obj, e->is_basic,
+                     e->basis, e->active2, e->trace, e->trace_cap, e->part_v, e->part_i);
+  LP_TRY(check_launch("k_pair_finalize"));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->profiling) {
+    if (e->ev_used + 2 > e->ev.size()) {
+      for (int k = 0; k < 2; k++) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreate(&ev));
+        e->ev.push_back(ev);
+      }
+    }
+    e0 = e->ev[e->ev_used++];
+    e1 = e->ev[e->ev_used++];
+    HIP_TRY(hipEventRecord(e0, e->stream));
+  }
+  const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
+  const int grid = e->update_grid;
+  if (n_slabs >= 16) launch_update_pair<16>(e, grid, e->update_nt);
+  else if (n_slabs >= 8) launch_update_pair<8>(e, grid, e->update_nt);
+  else if (n_slabs >= 4) launch_update_pair<4>(e, grid, e->update_nt);
+  else if (n_slabs >= 2) launch_update_pair<2>(e, grid, e->update_nt);
+  else launch_update_pair<1>(e, grid, e->update_nt);
+  LP_TRY(check_launch("k_update_pair"));
+  if (e->profiling) HIP_TRY(hipEventRecord(e1, e->stream));
+  return LPAMD_OK;
+}
+
 // ratio test (if the row is not known yet) + set-up + update for the candidate in `cand`
 int enqueue_pivot(lpamd_engine* e, bool find_row, Candidate* cand, const double* xcol, int64_t d_override, bool fuse_pr = false) {
   if (find_row) LP_TRY(enqueue_ratio_partial(e, false, cand, xcol));
@@ -411,6 +466,13 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
     const int rc = enqueue_update(e, false);
     e->update_slot = -1;
     return rc;
+  }
+  if (strategy == LPAMD_MAX_COST && e->pair_mode) {
+    // up to two pivots, one pass over the tableau (5 launches)
+    if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
+    LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
+    LP_TRY(enqueue_finalize(e, true, e->cand, nullptr, -1));
+    return enqueue_pair_tail(e);
   }
   if (strategy == LPAMD_MAX_COST) {
     // the previous pivot's set-up kernel already left the pricing partials of this iteration
@@ -439,10 +501,13 @@ int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   // With a budget the whole run is enqueued at once (kernels turn into no-ops
   // once the status leaves RUNNING); without one the batch grows geometrically.
   int64_t batch = budget >= 0 ? 1024 : 8;
+  const bool paired = strategy == LPAMD_MAX_COST && e->pair_mode;   // an iteration applies up to two pivots
+  e->last_loop_paired = paired;
   for (;;) {
     int64_t todo = batch;
     if (budget >= 0) todo = std::min<int64_t>(batch, e->h_st.max_iter - e->h_st.iter);
-    LP_TRY(ensure_trace(e, e->h_st.iter + todo));
+    if (paired) todo = (todo + 1) / 2;
+    LP_TRY(ensure_trace(e, e->h_st.iter + (paired ? 2 * todo : todo)));
     const int64_t before = e->h_st.iter;
     for (int64_t k = 0; k < todo; k++) LP_TRY(enqueue_iteration(e, strategy));
     LP_TRY(pull_state(e));
@@ -558,6 +623,12 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // (9460 against 9780 pivots/s), so it is taken up to 2048 rows
   e->two_launch = world == 1 && m <= 2048;
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
+  // Longer columns: a pivot is bound by the HBM pass, so two pivots share one (see k_update_pair)
+  e->pair_mode = world == 1 && !e->two_launch;
+  if (const char* env = getenv("LPAMD_PAIR")) {
+    e->pair_mode = world == 1 && atoi(env) != 0;
+    if (e->pair_mode) e->two_launch = false;
+  }
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
   } else {
@@ -579,6 +650,14 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
   HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda, e->stream));
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
+  HIP_TRY(hipMalloc(&e->pair, sizeof(PairInfo)));
+  HIP_TRY(hipMemsetAsync(e->pair, 0, sizeof(PairInfo), e->stream));
+  HIP_TRY(hipMalloc(&e->colv, sizeof(double) * e->sh.lda));
+  HIP_TRY(hipMalloc(&e->colp2, sizeof(double) * e->sh.lda));
+  HIP_TRY(hipMalloc(&e->rowp2, sizeof(double) * e->ncl));
+  HIP_TRY(hipMalloc(&e->active2, sizeof(int32_t) * e->ncl));
+  HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * e->sh.lda, e->stream));    // rows beyond m stay zero
+  HIP_TRY(hipMemsetAsync(e->colp2, 0, sizeof(double) * e->sh.lda, e->stream));
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->cand_la, sizeof(Candidate)));
   HIP_TRY(hipMemsetAsync(e->cand_la, 0xFF, sizeof(Candidate), e->stream));   // gcol = -1: no candidate
@@ -602,7 +681,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace};
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->pair, e->colv, e->colp2, e->rowp2, e->active2};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1037,9 +1116,30 @@ int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int
   e->ev_used = 0;
   LP_TRY(pull_state(e));
   e->prof_active = e->h_st.n_active;
+  if (e->last_loop_paired) {   // a pass that applied two pivots counts the columns of both
+    PairInfo pi;
+    LP_TRY(read_local(e, e->pair, &pi, sizeof(pi)));
+    if (pi.have2) e->prof_active += pi.n_second;
+  }
   if (total_ms) *total_ms = e->prof_ms;
   if (launches) *launches = e->prof_launches;
   if (active_columns) *active_columns = e->prof_active;
+  return LPAMD_OK;
+}
+
+int lpamd_pass_stats(lpamd_engine* e, int32_t* pivots, int64_t* streamed_columns, int64_t* touched_columns) {
+  CHECK_ENGINE(e);
+  LP_TRY(pull_state(e));
+  int32_t np = 1;
+  int64_t streamed = e->h_st.n_active, touched = e->h_st.n_active;
+  if (e->last_loop_paired) {
+    PairInfo pi;
+    LP_TRY(read_local(e, e->pair, &pi, sizeof(pi)));
+    if (pi.have2) { np = 2; streamed = e->h_st.n_active2; touched += pi.n_second; }
+  }
+  if (pivots) *pivots = np;
+  if (streamed_columns) *streamed_columns = streamed;
+  if (touched_columns) *touched_columns = touched;
   return LPAMD_OK;
 }
 

@@ -647,6 +647,208 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   }
 }
 
+// --------------------------------------------- two pivots per pass (MAX_COST)
+// Once k_pivot_finalize has set pivot A up, everything pivot B needs is known without
+// running A's rank-1 update: the objective row after A (pricing), the entering column of
+// B and the right-hand side as A's update will leave them (ratio test), and B's pivot row
+// after A.  Each of those is ONE column or ONE row, rebuilt with the update's own
+// arithmetic, flush(T (+) col'_A * row'_A).  The tableau is then streamed once and every
+// entry takes both rank-1 steps in their order,
+//   T[i][j] = flush(flush(T[i][j] + col'_A[i]*row'_A[j]) + col'_B[i]*row'_B[j]),
+// which is the same sequence of separately rounded operations as two passes: 16*m*n bytes
+// of HBM traffic for two pivots instead of one.  If B does not exist (budget reached,
+// optimum, no eligible row) the pass applies A alone and the next iteration of the loop
+// reports the outcome exactly as the one-pivot loop does.
+struct PairInfo {    // device resident: pivot B of the pass
+  int32_t have2;     // 1 once k_pair_finalize has set pivot B up
+  int32_t n_second;  // local columns with row'_B != 0
+  int64_t e2, r2, d2;
+  double a2, ce2, f2, g2;
+};
+
+// Pricing fold on the objective row after A, B's entering column as A's update will leave
+// it (written to colv, the tableau is not touched) and the ratio-test partials of
+// reference lp_simplex_tableau.cc:207-227 on it against the right-hand side after A.
+__global__ __launch_bounds__(kPartialThreads) void k_pair_ratio(
+    Tab T, Shape sh, PivotState* __restrict__ st, PairInfo* __restrict__ pair,
+    const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
+    const double* __restrict__ colp, const double* __restrict__ rowp, const double* __restrict__ rhs_next,
+    double* __restrict__ colv, double* __restrict__ rv, int64_t* __restrict__ ri) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (lead) { pair->have2 = 0; pair->n_second = 0; pair->e2 = -1; st->n_active2 = 0; }
+  if (st->iter >= st->max_iter) return;   // the budget ends with A
+  double ce;
+  int64_t l;
+  fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
+  if (l < 0) return;                      // optimal after A
+  if (lead) { pair->e2 = gcol_of(l * sh.world + sh.rank, sh.N); pair->ce2 = ce; }
+  const double* __restrict__ col = T.col(l);
+  const double rj = rowp[l];
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
+    double a = col[i];
+    if (rj != 0.0) a = flushz(__dadd_rn(a, __dmul_rn(colp[i], rj)));   // the update leaves columns with row' == 0 alone
+    colv[i] = a;
+    if ((float)a > -1e-6f) continue;
+    const double ratio = rhs_next[i] / (-a);
+    if (bv > ratio) { bv = ratio; bi = i; }
+  }
+  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) { rv[blockIdx.x] = bv; ri[blockIdx.x] = bi; }
+}
+
+// Set-up of pivot B (reference lp_simplex_tableau.cc:10-44 on the tableau after A): row fold,
+// scalars, col'_B, the pivot row after A gathered with A's step applied on the fly, row'_B,
+// the objective row, the list of columns either step touches, the pricing partials of the
+// iteration after B.  st->e/r/d keep describing A until the update kernel has used them.
+__global__ __launch_bounds__(kPartialThreads) void k_pair_finalize(
+    Tab T, Shape sh, PivotState* __restrict__ st, PairInfo* __restrict__ pair,
+    const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
+    const double* __restrict__ colp, const double* __restrict__ rowp, const double* __restrict__ colv,
+    double* __restrict__ colp2, double* __restrict__ rowp2, double* __restrict__ obj,
+    const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis, int32_t* __restrict__ active2,
+    int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (st->status != ST_RUNNING) return;
+  const int64_t e2 = pair->e2;
+  if (e2 < 0) return;
+  double best;
+  int64_t r2;
+  fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2, s_v, s_i);
+  if (r2 < 0) return;   // unbounded after A: found again, and reported, by the next iteration
+  const double ce2 = pair->ce2;
+  const double a2 = colv[r2];
+  const double f2 = -1.0 / a2;
+  const double g2 = __dmul_rn(ce2, f2);
+  if ((int)blockIdx.x < n_row_blocks) {
+    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads)
+      colp2[i] = (i == r2) ? __dadd_rn(1.0, a2) : colv[i];
+    return;
+  }
+  const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
+  const int ncl = sh.nloc + 1;
+  const int64_t e1 = st->e, d1 = st->d, r1 = st->r;
+  const int64_t d2 = (r2 == r1) ? e1 : basis[r2];   // basis[r1] is flipped by the update kernel
+  auto local_id = [&](int64_t g) -> int {
+    if (g < 0 || g == sh.N) return -1;
+    const int64_t o = ordinal_of(g, sh.N);
+    return (o % sh.world == sh.rank) ? (int)(o / sh.world) : -1;
+  };
+  const int l_e1 = local_id(e1), l_d1 = local_id(d1), l_e2 = local_id(e2), l_d2 = local_id(d2);
+  const double c1r = colp[r2];   // col'_A[r2]
+  double nbv = -DBL_MAX;
+  int64_t nbi = -1;
+  for (int l0 = cb * kPartialThreads; l0 < ncl; l0 += n_cb * kPartialThreads) {
+    const int l = l0 + threadIdx.x;
+    bool act = false, second = false;
+    if (l < ncl) {
+      double t = T.col(l)[r2];
+      const double r1j = rowp[l];
+      if (r1j != 0.0) t = flushz(__dadd_rn(t, __dmul_rn(c1r, r1j)));
+      const double rp2 = __dmul_rn(t, f2);
+      double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g2)));
+      if (l == l_e2) o = 0.0;
+      obj[l] = o;
+      rowp2[l] = rp2;
+      second = rp2 != 0.0;
+      act = second || r1j != 0.0;
+      if (l < sh.nloc) {
+        bool basic = is_basic[l] != 0;
+        if (l == l_e1) basic = true; else if (l == l_d1) basic = false;
+        if (l == l_e2) basic = true; else if (l == l_d2) basic = false;
+        if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
+      }
+    }
+    const unsigned long long mask = __ballot(act);
+    const unsigned long long mask2 = __ballot(second);
+    if (mask) {
+      const int lane = threadIdx.x & (kWave - 1);
+      const int leader = __ffsll((long long)mask) - 1;
+      int base = 0;
+      if (lane == leader) {
+        base = atomicAdd(&st->n_active2, __popcll(mask));
+        if (mask2) atomicAdd(&pair->n_second, __popcll(mask2));
+      }
+      base = __shfl(base, leader, kWave);
+      if (act) active2[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+    }
+  }
+  block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
+  if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
+  if (cb == 0 && threadIdx.x == 0) {
+    pair->r2 = r2; pair->d2 = d2; pair->a2 = a2; pair->f2 = f2; pair->g2 = g2;
+    pair->have2 = 1;
+    const int64_t it = st->iter;
+    if (it < trace_cap) { trace[2 * it] = e2; trace[2 * it + 1] = r2; }
+    st->iter = it + 1;
+  }
+}
+
+// The pass itself: A alone over A's list, or both steps over the union list.
+template <int kUnroll, bool kNT>
+__global__ __launch_bounds__(kUpdateThreads, 2) void k_update_pair(
+    Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, const int32_t* __restrict__ active,
+    const double* __restrict__ colp2, const double* __restrict__ rowp2, const int32_t* __restrict__ active2,
+    PivotState* __restrict__ st, const PairInfo* __restrict__ pair, Shape sh,
+    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
+  if (st->status != ST_RUNNING) return;
+  const bool two = pair->have2 != 0;
+  const int n_list = two ? st->n_active2 : st->n_active;
+  const int32_t* __restrict__ list = two ? active2 : active;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    // bookkeeping of reference lp_simplex_tableau.cc:16-28, A then B
+    auto flip = [&](int64_t e, int64_t d, int64_t r) {
+      const int64_t eo = ordinal_of(e, sh.N);
+      if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+      if (d >= 0 && d != sh.N) {
+        const int64_t dord = ordinal_of(d, sh.N);
+        if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+      }
+      basis[r] = e;
+    };
+    flip(st->e, st->d, st->r);
+    if (two) {
+      flip(pair->e2, pair->d2, pair->r2);
+      st->e = pair->e2; st->r = pair->r2; st->d = pair->d2;   // no other workgroup of this launch reads these
+      st->a = pair->a2; st->ce = pair->ce2; st->f = pair->f2; st->g = pair->g2;
+    }
+  }
+  const int n_vec = (int)(lda / 2);
+  const double2* __restrict__ cp1 = reinterpret_cast<const double2*>(colp);
+  const double2* __restrict__ cp2 = reinterpret_cast<const double2*>(colp2);
+  for (int k = blockIdx.x; k < n_list; k += gridDim.x) {
+    const int l = list[k];
+    const double r1 = rowp[l];
+    const double r2 = two ? rowp2[l] : 0.0;
+    const bool s1 = r1 != 0.0, s2 = r2 != 0.0;   // uniform over the workgroup
+    double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l));
+    int v = threadIdx.x;
+    for (; v + (kUnroll - 1) * kUpdateThreads < n_vec; v += kUnroll * kUpdateThreads) {
+      double2 t[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) t[u] = ld16<kNT>(p + v + u * kUpdateThreads);
+      __builtin_amdgcn_sched_barrier(0);   // all loads of the batch before its first store
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) {
+        if (s1) t[u] = rank1(t[u], cp1[v + u * kUpdateThreads], r1);
+        if (s2) t[u] = rank1(t[u], cp2[v + u * kUpdateThreads], r2);
+        st16<kNT>(p + v + u * kUpdateThreads, t[u]);
+      }
+    }
+    for (; v < n_vec; v += kUpdateThreads) {
+      double2 o = ld16<kNT>(p + v);
+      if (s1) o = rank1(o, cp1[v], r1);
+      if (s2) o = rank1(o, cp2[v], r2);
+      st16<kNT>(p + v, o);
+    }
+  }
+}
+
 // ------------------------------------------------- multi-GPU exchange helpers
 // Every rank folds the all-gathered candidate records identically (same rule as
 // lpamd_fold_candidates on the host) and keeps the winner in its own `cand`, so

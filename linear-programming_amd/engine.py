@@ -68,6 +68,7 @@ def library():
         "lpamd_trace": (ctypes.c_int, [vp, vp, vp, i64, P(i64)]),
         "lpamd_set_profiling": (ctypes.c_int, [vp, i32]),
         "lpamd_update_stats": (ctypes.c_int, [vp, P(ctypes.c_double), P(i64), P(i64)]),
+        "lpamd_pass_stats": (ctypes.c_int, [vp, P(ctypes.c_int32), P(i64), P(i64)]),
         "lpamd_local_candidate": (ctypes.c_int, [vp, i32, vp]),
         "lpamd_select_candidate": (ctypes.c_int, [vp, i32, vp, i32, P(i64), P(i64), P(i32), P(i32)]),
         "lpamd_fold_candidates": (ctypes.c_int, [i32, vp, i32, i64, P(i64), P(i64), P(i32), P(i32), vp]),
@@ -250,6 +251,12 @@ class TableauEngine:
         ms, n, act = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64()
         _ck(self.L.lpamd_update_stats(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(act)))
         return ms.value, n.value, act.value
+
+    def pass_stats(self):
+        """(pivots applied by the last pass over the tableau, columns it streamed, columns the pivots touch one by one)"""
+        k, s, t = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_pass_stats(self.h, ctypes.byref(k), ctypes.byref(s), ctypes.byref(t)))
+        return k.value, s.value, t.value
 
     # ---- multi-GPU steps (device pointers are plain ints, e.g. tensor.data_ptr()) ----
     def local_candidate(self, strategy, cand_ptr):

@@ -1,0 +1,129 @@
+"""GPU parity of the loop that applies two MAX_COST pivots per pass over the tableau
+(k_pair_ratio / k_pair_finalize / k_update_pair), forced on inputs the oracle solves fully:
+trace, tableau, objective row and basis flags must be bit-identical to one pivot per pass."""
+import numpy as np
+import pytest
+
+from cases import all_cases, case_golden, case_text
+from oracle import lp_frontend as fe
+from oracle import lp_oracle as lo
+from test_engine_parity import _random_tied_lp, assert_same_tableau, bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _pair_loop(monkeypatch):
+    monkeypatch.setenv("LPAMD_PAIR", "1")
+
+
+@pytest.mark.parametrize("name", sorted({n for n, s in all_cases() if s == "max_cost"}))
+def test_goldens_two_pivots_per_pass(lpamd, name):
+    tab, dt = lo.from_text(case_text(name))
+    want = dt.solve(lo.MAX_COST)
+    eng = lpamd.TableauEngine(tab.m, tab.N)
+    eng.upload(tab.T, tab.obj, tab.is_basic)
+    res, n = eng.solve(lpamd.MAX_COST)
+    assert res == want == lpamd.SOLVED and n == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    x = eng.column_values()
+    assert np.array_equal(bits(x), bits(dt.column_values()))
+    out = fe.format_solution(tab, x, eng.objective_constant())
+    assert out.rstrip("\n") == case_golden(name, "max_cost").rstrip("\n")
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_lps_with_ties_two_pivots_per_pass(lpamd, seed):
+    rng = np.random.default_rng(seed)
+    text = _random_tied_lp(rng, int(rng.integers(3, 12)), int(rng.integers(2, 10)))
+    tab, dt = lo.from_text(text)
+    want = dt.solve(lo.MAX_COST)
+    eng = lpamd.TableauEngine(tab.m, tab.N)
+    eng.upload(tab.T, tab.obj, tab.is_basic)
+    res, n = eng.solve(lpamd.MAX_COST)
+    assert res == want, text
+    assert eng.trace() == dt.trace(), text
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+def test_budgets_odd_even_and_continuation(lpamd):
+    """A budget that ends after the first pivot of a pass, after the second, and runs that go on
+    from either state; then to the optimum."""
+    m, n = 600, 1100
+    dt = lo.DenseTableau.synthetic(m, n, 7)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, 7)
+    total = 0
+    for k in (1, 2, 37, 1, 1, 4, 3):
+        res, done = eng.run_pivots(lpamd.MAX_COST, k)
+        total += k
+        assert (res, done) == (lpamd.LIMIT, k)
+        assert dt.solve(lo.MAX_COST, max_pivots=total) == lo.LIMIT
+        assert eng.pivot_count() == total
+        assert eng.trace() == dt.trace()
+        assert_same_tableau(eng, dt)
+        pivots, streamed, touched = eng.pass_stats()
+        assert pivots == (1 if k % 2 else 2) and streamed <= touched <= 2 * streamed
+    res, done = eng.run_pivots(lpamd.MAX_REDUCTION, 5)     # the other strategy in between
+    assert (res, done) == (lpamd.LIMIT, 5)
+    assert dt.solve(lo.MAX_REDUCTION, max_pivots=total + 5) == lo.LIMIT
+    assert_same_tableau(eng, dt)
+    res, _ = eng.solve(lpamd.MAX_COST)
+    assert res == dt.solve(lo.MAX_COST) == lpamd.SOLVED
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (1, 5), (3, 1), (511, 2), (512, 3), (513, 3), (2, 700), (2500, 40)])
+def test_extreme_shapes_two_pivots_per_pass(lpamd, m, n):
+    dt = lo.DenseTableau.synthetic(m, n, 2)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, 2)
+    res, _ = eng.solve(lpamd.MAX_COST)
+    assert res == dt.solve(lo.MAX_COST)
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+def test_unbounded_found_by_the_second_pivot_of_a_pass(lpamd):
+    # after x1 enters (row 0), x2 has no eligible row: the pass applies the first pivot alone
+    tab, dt = lo.from_text("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n")
+    eng = lpamd.TableauEngine(tab.m, tab.N)
+    eng.upload(tab.T, tab.obj, tab.is_basic)
+    assert eng.solve(lpamd.MAX_COST)[0] == dt.solve(lo.MAX_COST) == lpamd.UNBOUNDED
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+def test_default_loop_pairs_long_columns(lpamd, monkeypatch):
+    """m > 2048 on one GPU takes the paired loop by default; LPAMD_PAIR=0 gives the same bits."""
+    m, n, k = 2304, 1500, 41
+    monkeypatch.delenv("LPAMD_PAIR")
+    a = lpamd.TableauEngine(m, n + m)
+    a.fill_synthetic(n, 5)
+    assert a.run_pivots(lpamd.MAX_COST, k) == (lpamd.LIMIT, k)
+    assert a.pass_stats()[0] == 1          # 41st pivot alone in the last pass
+    assert a.run_pivots(lpamd.MAX_COST, k + 1) == (lpamd.LIMIT, k + 1)
+    assert a.pass_stats()[0] == 2
+    monkeypatch.setenv("LPAMD_PAIR", "0")
+    b = lpamd.TableauEngine(m, n + m)
+    b.fill_synthetic(n, 5)
+    assert b.run_pivots(lpamd.MAX_COST, 2 * k + 1) == (lpamd.LIMIT, 2 * k + 1)
+    assert b.pass_stats()[0] == 1
+    assert a.trace() == b.trace()
+    ta, tb = a.download(), b.download()
+    for x, y in zip(ta[:2], tb[:2]):
+        assert np.array_equal(bits(x), bits(y))
+    assert np.array_equal(ta[2], tb[2])
+    dt = lo.DenseTableau.synthetic(m, n, 5)
+    assert dt.solve(lo.MAX_COST, max_pivots=2 * k + 1) == lo.LIMIT
+    assert a.trace() == dt.trace()
+    assert_same_tableau(a, dt)
+    a.close()
+    b.close()
