@@ -123,13 +123,13 @@ int lpamd_trace(const lpamd_engine* eng, int64_t* e, int64_t* r, int64_t cap, in
 /* HIP-event timing of the rank-1 update kernel (off by default). */
 int lpamd_set_profiling(lpamd_engine* eng, int32_t on);
 int lpamd_update_stats(lpamd_engine* eng, double* total_ms, int64_t* launches, int64_t* active_columns);
-/* The device loop of lpamd_run_pivots / lpamd_solve applies up to two MAX_COST pivots per
- * pass over the tableau (one GPU, m > 2048; LPAMD_PAIR=0/1 overrides): the second pivot's
- * column and row are rebuilt from the first one's col'/row' (the arithmetic of reference
- * lp_simplex_tableau.cc:33-46, entry by entry in the same order), so the results are those
- * of two passes.  For the last pass: the pivots it applied (1 or 2), the columns it
- * streamed, and the sum of the columns the pivots touch one by one (what
- * lpamd_update_stats reports as active_columns). */
+/* The device loop of lpamd_run_pivots / lpamd_solve applies a chain of up to 8 MAX_COST
+ * pivots per pass over the tableau (one GPU, m > 2048; LPAMD_CHAIN=1..8 overrides): the
+ * column and the row of every further pivot are rebuilt from the col'/row' vectors of the
+ * pivots before it (the arithmetic of reference lp_simplex_tableau.cc:33-46, entry by entry
+ * in the same order), so the results are those of one pass per pivot.  For the last pass:
+ * the pivots it applied, the columns it streamed, and the sum of the columns the pivots
+ * touch one by one (what lpamd_update_stats reports as active_columns). */
 int lpamd_pass_stats(lpamd_engine* eng, int32_t* pivots, int64_t* streamed_columns, int64_t* touched_columns);
 
 /* ---- multi-GPU steps (column shards; the caller runs the collectives) ----

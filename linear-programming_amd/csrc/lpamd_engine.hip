@@ -66,14 +66,16 @@ struct lpamd_engine {
   bool two_launch = false;
   int price_buf = 0;            // which half of part_v/part_i holds the fresh pricing partials (two-launch loop)
   int update_slot = -1;         // counter slot handed to the next k_update launch (-1: three-launch loop)
-  // Two pivots per pass over the tableau (MAX_COST on one GPU, columns too long for the two-launch loop)
-  bool pair_mode = false;
-  bool last_loop_paired = false;
-  PairInfo* pair = nullptr;
-  double* colv = nullptr;       // entering column of the second pivot as the first one's update will leave it
-  double* colp2 = nullptr;      // col' and row' of the second pivot, list of columns either pivot touches
-  double* rowp2 = nullptr;
-  int32_t* active2 = nullptr;
+  // Several pivots per pass over the tableau (MAX_COST on one GPU, columns too long for the two-launch loop):
+  // colp holds chain_depth col' vectors (lda apart), rowp chain_depth row' vectors (rstride apart)
+  int32_t chain_depth = 1;      // pivots a pass may apply (1: one pivot per pass)
+  int32_t loop_depth = 1;       // depth of the device loop that ran last
+  int32_t slab_shape = 0;       // k_update_slab variant (0: k_update_chain)
+  int32_t slab_grid = 4096;
+  int64_t rstride = 0;
+  ChainStep* steps = nullptr;   // [kMaxChain]
+  double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
+  int32_t* lists = nullptr;     // [2 * ncl]: columns touched by the steps so far, alternating per step
   int64_t slot_counter = 0;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -395,27 +397,58 @@ int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* can
 }
 
 template <int kUnroll>
-void launch_update_pair(lpamd_engine* e, int grid, bool nt) {
+void launch_update_chain(lpamd_engine* e, int grid, bool nt) {
   if (nt)
-    hipLaunchKernelGGL((k_update_pair<kUnroll, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
-                       e->active, e->colp2, e->rowp2, e->active2, e->st, e->pair, e->sh, e->is_basic, e->basis);
+    hipLaunchKernelGGL((k_update_chain<kUnroll, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
+                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis);
   else
-    hipLaunchKernelGGL((k_update_pair<kUnroll, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
-                       e->active, e->colp2, e->rowp2, e->active2, e->st, e->pair, e->sh, e->is_basic, e->basis);
+    hipLaunchKernelGGL((k_update_chain<kUnroll, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
+                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis);
 }
 
-// Second pivot of a pass (pricing fold + virtual column + ratio partials, set-up) and the pass itself,
-// for the pivot that k_pivot_finalize has just set up.
-int enqueue_pair_tail(lpamd_engine* e) {
+// col' in registers: chains of 4 and 8, slab shape (kR, kC) chosen by e->slab_shape; false: not applicable
+template <int kK, int kR, int kC>
+void launch_slab(lpamd_engine* e) {
+  const int n_slabs = (int)(e->sh.lda / (2 * kUpdateThreads * kR));
+  const int n_grp = std::max(1, std::min((e->ncl + kC - 1) / kC, std::max(1, e->slab_grid / n_slabs)));
+  const int grid = n_slabs * n_grp;
+  if (e->update_nt)
+    hipLaunchKernelGGL((k_update_slab<kK, kR, kC, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
+                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis, n_slabs);
+  else
+    hipLaunchKernelGGL((k_update_slab<kK, kR, kC, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
+                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis, n_slabs);
+}
+template <int kK>
+bool launch_slab_shape(lpamd_engine* e) {
+  switch (e->slab_shape) {
+    case 1: launch_slab<kK, 1, 8>(e); return true;
+    case 2: launch_slab<kK, 1, 16>(e); return true;
+    case 3: if (e->sh.lda % 1024) return false; launch_slab<kK, 2, 4>(e); return true;
+    case 4: if (e->sh.lda % 1024) return false; launch_slab<kK, 2, 8>(e); return true;
+    default: return false;
+  }
+}
+bool launch_update_slab(lpamd_engine* e) {
+  if (e->chain_depth == 4) return launch_slab_shape<4>(e);
+  if (e->chain_depth == 8) return launch_slab_shape<8>(e);
+  return false;
+}
+
+// The further pivots of a pass (per step: pricing fold + rebuilt column + ratio partials, then set-up) and
+// the pass itself, for the pivot that k_pivot_finalize has just set up.
+int enqueue_chain_tail(lpamd_engine* e, int depth) {
   double* rv = e->part_v + kMaxPartials;
   int64_t* ri = e->part_i + kMaxPartials;
-  hipLaunchKernelGGL(k_pair_ratio, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->pair, e->part_v,
-                     e->part_i, e->n_price_part, e->colp, e->rowp, e->rhs_next, e->colv, rv, ri);
-  LP_TRY(check_launch("k_pair_ratio"));
-  hipLaunchKernelGGL(k_pair_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
-                     e->pair, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->colv, e->colp2, e->rowp2, e->obj, e->is_basic,
-                     e->basis, e->active2, e->trace, e->trace_cap, e->part_v, e->part_i);
-  LP_TRY(check_launch("k_pair_finalize"));
+  for (int j = 1; j < depth; j++) {
+    hipLaunchKernelGGL(k_chain_ratio, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
+                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->colv, rv, ri);
+    LP_TRY(check_launch("k_chain_ratio"));
+    hipLaunchKernelGGL(k_chain_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
+                       e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->colv, e->obj, e->is_basic,
+                       e->basis, e->lists, e->trace, e->trace_cap, e->part_v, e->part_i);
+    LP_TRY(check_launch("k_chain_finalize"));
+  }
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->ev_used + 2 > e->ev.size()) {
@@ -431,12 +464,13 @@ int enqueue_pair_tail(lpamd_engine* e) {
   }
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
   const int grid = e->update_grid;
-  if (n_slabs >= 16) launch_update_pair<16>(e, grid, e->update_nt);
-  else if (n_slabs >= 8) launch_update_pair<8>(e, grid, e->update_nt);
-  else if (n_slabs >= 4) launch_update_pair<4>(e, grid, e->update_nt);
-  else if (n_slabs >= 2) launch_update_pair<2>(e, grid, e->update_nt);
-  else launch_update_pair<1>(e, grid, e->update_nt);
-  LP_TRY(check_launch("k_update_pair"));
+  if (launch_update_slab(e)) { /* col' in registers */ }
+  else if (n_slabs >= 16) launch_update_chain<16>(e, grid, e->update_nt);
+  else if (n_slabs >= 8) launch_update_chain<8>(e, grid, e->update_nt);
+  else if (n_slabs >= 4) launch_update_chain<4>(e, grid, e->update_nt);
+  else if (n_slabs >= 2) launch_update_chain<2>(e, grid, e->update_nt);
+  else launch_update_chain<1>(e, grid, e->update_nt);
+  LP_TRY(check_launch("k_update_chain"));
   if (e->profiling) HIP_TRY(hipEventRecord(e1, e->stream));
   return LPAMD_OK;
 }
@@ -467,12 +501,12 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
     e->update_slot = -1;
     return rc;
   }
-  if (strategy == LPAMD_MAX_COST && e->pair_mode) {
-    // up to two pivots, one pass over the tableau (5 launches)
+  if (strategy == LPAMD_MAX_COST && e->chain_depth > 1) {
+    // up to chain_depth pivots, one pass over the tableau (2 * chain_depth + 1 launches)
     if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
     LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
     LP_TRY(enqueue_finalize(e, true, e->cand, nullptr, -1));
-    return enqueue_pair_tail(e);
+    return enqueue_chain_tail(e, e->chain_depth);
   }
   if (strategy == LPAMD_MAX_COST) {
     // the previous pivot's set-up kernel already left the pricing partials of this iteration
@@ -501,13 +535,13 @@ int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   // With a budget the whole run is enqueued at once (kernels turn into no-ops
   // once the status leaves RUNNING); without one the batch grows geometrically.
   int64_t batch = budget >= 0 ? 1024 : 8;
-  const bool paired = strategy == LPAMD_MAX_COST && e->pair_mode;   // an iteration applies up to two pivots
-  e->last_loop_paired = paired;
+  const int64_t depth = strategy == LPAMD_MAX_COST ? e->chain_depth : 1;   // pivots an iteration may apply
+  e->loop_depth = (int32_t)depth;
   for (;;) {
     int64_t todo = batch;
     if (budget >= 0) todo = std::min<int64_t>(batch, e->h_st.max_iter - e->h_st.iter);
-    if (paired) todo = (todo + 1) / 2;
-    LP_TRY(ensure_trace(e, e->h_st.iter + (paired ? 2 * todo : todo)));
+    todo = (todo + depth - 1) / depth;
+    LP_TRY(ensure_trace(e, e->h_st.iter + depth * todo));
     const int64_t before = e->h_st.iter;
     for (int64_t k = 0; k < todo; k++) LP_TRY(enqueue_iteration(e, strategy));
     LP_TRY(pull_state(e));
@@ -623,12 +657,17 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // (9460 against 9780 pivots/s), so it is taken up to 2048 rows
   e->two_launch = world == 1 && m <= 2048;
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
-  // Longer columns: a pivot is bound by the HBM pass, so two pivots share one (see k_update_pair)
-  e->pair_mode = world == 1 && !e->two_launch;
-  if (const char* env = getenv("LPAMD_PAIR")) {
-    e->pair_mode = world == 1 && atoi(env) != 0;
-    if (e->pair_mode) e->two_launch = false;
+  // Longer columns: a pivot is bound by the HBM pass, so a chain of pivots shares one (see k_update_chain)
+  e->chain_depth = (world == 1 && !e->two_launch) ? 8 : 1;
+  if (const char* env = getenv("LPAMD_CHAIN")) {
+    e->chain_depth = world == 1 ? std::max(1, std::min(kMaxChain, atoi(env))) : 1;
+    if (e->chain_depth > 1) e->two_launch = false;
   }
+  // Measured (scripts/slab_sweep.sh, m=32768 n=65536, chain of 8): col' from L2 8.44 ms per pass; in registers with
+  // 512-row slabs x 8 columns in flight 6.68 ms, 1024-row slabs x 4 columns 5.68 ms (the HBM time of one pass again)
+  e->slab_shape = e->sh.lda % 1024 == 0 ? 3 : 1;
+  if (const char* env = getenv("LPAMD_SLAB")) e->slab_shape = atoi(env);
+  if (const char* env = getenv("LPAMD_SLAB_GRID")) e->slab_grid = std::max(1, atoi(env));
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
   } else {
@@ -639,8 +678,9 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMalloc(&e->obj, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->is_basic, e->ncl));
   HIP_TRY(hipMalloc(&e->basis, sizeof(int64_t) * m));
-  HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda));
-  HIP_TRY(hipMalloc(&e->rowp, sizeof(double) * std::max<int64_t>(e->ncl, e->sh.lda)));
+  e->rstride = std::max<int64_t>(e->ncl, e->sh.lda);
+  HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda * e->chain_depth));
+  HIP_TRY(hipMalloc(&e->rowp, sizeof(double) * e->rstride * e->chain_depth));
   HIP_TRY(hipMalloc(&e->active, sizeof(int32_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
@@ -650,14 +690,11 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
   HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda, e->stream));
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
-  HIP_TRY(hipMalloc(&e->pair, sizeof(PairInfo)));
-  HIP_TRY(hipMemsetAsync(e->pair, 0, sizeof(PairInfo), e->stream));
+  HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
+  HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
   HIP_TRY(hipMalloc(&e->colv, sizeof(double) * e->sh.lda));
-  HIP_TRY(hipMalloc(&e->colp2, sizeof(double) * e->sh.lda));
-  HIP_TRY(hipMalloc(&e->rowp2, sizeof(double) * e->ncl));
-  HIP_TRY(hipMalloc(&e->active2, sizeof(int32_t) * e->ncl));
+  HIP_TRY(hipMalloc(&e->lists, sizeof(int32_t) * 2 * e->ncl));
   HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * e->sh.lda, e->stream));    // rows beyond m stay zero
-  HIP_TRY(hipMemsetAsync(e->colp2, 0, sizeof(double) * e->sh.lda, e->stream));
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->cand_la, sizeof(Candidate)));
   HIP_TRY(hipMemsetAsync(e->cand_la, 0xFF, sizeof(Candidate), e->stream));   // gcol = -1: no candidate
@@ -668,7 +705,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
   e->n_row_blocks = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
   HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
-  HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda, e->stream));
+  HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * e->chain_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));
   std::memset(&e->h_st, 0, sizeof(PivotState));
   LP_TRY(ensure_trace(e, 4096));
@@ -681,7 +718,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->pair, e->colv, e->colp2, e->rowp2, e->active2};
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->lists};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1116,10 +1153,10 @@ int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int
   e->ev_used = 0;
   LP_TRY(pull_state(e));
   e->prof_active = e->h_st.n_active;
-  if (e->last_loop_paired) {   // a pass that applied two pivots counts the columns of both
-    PairInfo pi;
-    LP_TRY(read_local(e, e->pair, &pi, sizeof(pi)));
-    if (pi.have2) e->prof_active += pi.n_second;
+  if (e->loop_depth > 1) {   // a pass that applied several pivots counts the columns of each
+    ChainStep cs[kMaxChain];
+    LP_TRY(read_local(e, e->steps, cs, sizeof(cs)));
+    for (int s = 1; s < e->loop_depth && cs[s].done; s++) e->prof_active += cs[s].n_touched;
   }
   if (total_ms) *total_ms = e->prof_ms;
   if (launches) *launches = e->prof_launches;
@@ -1132,10 +1169,10 @@ int lpamd_pass_stats(lpamd_engine* e, int32_t* pivots, int64_t* streamed_columns
   LP_TRY(pull_state(e));
   int32_t np = 1;
   int64_t streamed = e->h_st.n_active, touched = e->h_st.n_active;
-  if (e->last_loop_paired) {
-    PairInfo pi;
-    LP_TRY(read_local(e, e->pair, &pi, sizeof(pi)));
-    if (pi.have2) { np = 2; streamed = e->h_st.n_active2; touched += pi.n_second; }
+  if (e->loop_depth > 1) {
+    ChainStep cs[kMaxChain];
+    LP_TRY(read_local(e, e->steps, cs, sizeof(cs)));
+    for (int s = 1; s < e->loop_depth && cs[s].done; s++) { np = s + 1; streamed = cs[s].n_list; touched += cs[s].n_touched; }
   }
   if (pivots) *pivots = np;
   if (streamed_columns) *streamed_columns = streamed;

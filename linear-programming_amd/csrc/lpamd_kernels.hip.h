@@ -647,100 +647,142 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   }
 }
 
-// --------------------------------------------- two pivots per pass (MAX_COST)
-// Once k_pivot_finalize has set pivot A up, everything pivot B needs is known without
-// running A's rank-1 update: the objective row after A (pricing), the entering column of
-// B and the right-hand side as A's update will leave them (ratio test), and B's pivot row
-// after A.  Each of those is ONE column or ONE row, rebuilt with the update's own
-// arithmetic, flush(T (+) col'_A * row'_A).  The tableau is then streamed once and every
-// entry takes both rank-1 steps in their order,
-//   T[i][j] = flush(flush(T[i][j] + col'_A[i]*row'_A[j]) + col'_B[i]*row'_B[j]),
-// which is the same sequence of separately rounded operations as two passes: 16*m*n bytes
-// of HBM traffic for two pivots instead of one.  If B does not exist (budget reached,
-// optimum, no eligible row) the pass applies A alone and the next iteration of the loop
-// reports the outcome exactly as the one-pivot loop does.
-struct PairInfo {    // device resident: pivot B of the pass
-  int32_t have2;     // 1 once k_pair_finalize has set pivot B up
-  int32_t n_second;  // local columns with row'_B != 0
-  int64_t e2, r2, d2;
-  double a2, ce2, f2, g2;
+// ------------------------------------------ several pivots per pass (MAX_COST)
+// Once k_pivot_finalize has set pivot 0 of a pass up, everything the next pivot needs is
+// known without running the rank-1 update: the objective row after pivot 0 (pricing), the
+// next entering column and the right-hand side as the update will leave them (ratio
+// test), and the next pivot row.  Each of those is ONE column or ONE row, rebuilt with the
+// update's own arithmetic, flush(T (+) col'_0 * row'_0); the same holds again after the
+// second pivot has been set up, and so on.  A pass sets up a chain of up to kMaxChain pivots
+// this way and then streams the tableau ONCE; every entry takes the rank-1 steps of the
+// chain in their order,
+//   T[i][j] = flush(... flush(flush(T[i][j] + col'_0[i]*row'_0[j]) + col'_1[i]*row'_1[j]) ...),
+// which is the same sequence of separately rounded operations as one pass per pivot:
+// 16*m*n bytes of HBM traffic for the whole chain.  The chain ends early when the budget
+// is used up, at the optimum or when a column has no eligible row; the pass then applies
+// what has been set up and the next iteration of the loop reports the outcome exactly as
+// the one-pivot loop does.  Step s keeps col'_s at colp + s*lda and row'_s at rowp + s*rstride.
+constexpr int kMaxChain = 8;
+
+struct ChainStep {   // pivots 1.. of the pass (pivot 0 is described by PivotState)
+  int32_t done;      // 1 once k_chain_finalize has set the step up
+  int32_t n_touched; // local columns with row'_s != 0
+  int32_t n_list;    // length of the list of columns touched by steps 0..s
+  int32_t pad;
+  int64_t e, r, d;
+  double a, ce, f, g;
 };
 
-// Pricing fold on the objective row after A, B's entering column as A's update will leave
-// it (written to colv, the tableau is not touched) and the ratio-test partials of
-// reference lp_simplex_tableau.cc:207-227 on it against the right-hand side after A.
-__global__ __launch_bounds__(kPartialThreads) void k_pair_ratio(
-    Tab T, Shape sh, PivotState* __restrict__ st, PairInfo* __restrict__ pair,
+__device__ __forceinline__ double chain_apply(double v, int j, const double* __restrict__ colp, int64_t lda, int64_t i,
+                                              const double* rs) {
+#pragma unroll
+  for (int s = 0; s < kMaxChain - 1; s++)
+    if (s < j && rs[s] != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(colp[s * lda + i], rs[s])));   // the update leaves columns with row' == 0 alone
+  return v;
+}
+
+// Step j >= 1: pricing fold on the objective row after step j-1, the entering column and the
+// right-hand side as steps 0..j-1 will leave them (column written to colv, the tableau is not
+// touched) and the ratio-test partials of reference lp_simplex_tableau.cc:207-227 on them.
+__global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
+    Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
     const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
-    const double* __restrict__ colp, const double* __restrict__ rowp, const double* __restrict__ rhs_next,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
     double* __restrict__ colv, double* __restrict__ rv, int64_t* __restrict__ ri) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
-  if (lead) { pair->have2 = 0; pair->n_second = 0; pair->e2 = -1; st->n_active2 = 0; }
-  if (st->iter >= st->max_iter) return;   // the budget ends with A
+  if (j == 1) {
+    if (lead) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].n_touched = 0; steps[s].n_list = 0; steps[s].e = -1; }
+  } else if (!steps[j - 1].done) {
+    return;                               // the chain ended before this step
+  }
+  if (st->iter >= st->max_iter) return;   // the budget ends with step j-1
   double ce;
   int64_t l;
   fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
-  if (l < 0) return;                      // optimal after A
-  if (lead) { pair->e2 = gcol_of(l * sh.world + sh.rank, sh.N); pair->ce2 = ce; }
+  if (l < 0) return;                      // optimal after step j-1
+  if (lead) { steps[j].e = gcol_of(l * sh.world + sh.rank, sh.N); steps[j].ce = ce; }
   const double* __restrict__ col = T.col(l);
-  const double rj = rowp[l];
+  const double* __restrict__ rhs = T.col(sh.nloc);
+  double rs_c[kMaxChain - 1], rs_b[kMaxChain - 1];
+#pragma unroll
+  for (int s = 0; s < kMaxChain - 1; s++) {
+    rs_c[s] = s < j ? rowp[s * rstride + l] : 0.0;
+    rs_b[s] = s < j ? rowp[s * rstride + sh.nloc] : 0.0;
+  }
   double bv = DBL_MAX;
   int64_t bi = -1;
   for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
-    double a = col[i];
-    if (rj != 0.0) a = flushz(__dadd_rn(a, __dmul_rn(colp[i], rj)));   // the update leaves columns with row' == 0 alone
+    const double a = chain_apply(col[i], j, colp, sh.lda, i, rs_c);
     colv[i] = a;
     if ((float)a > -1e-6f) continue;
-    const double ratio = rhs_next[i] / (-a);
+    const double b = chain_apply(rhs[i], j, colp, sh.lda, i, rs_b);
+    const double ratio = b / (-a);
     if (bv > ratio) { bv = ratio; bi = i; }
   }
   block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
   if (threadIdx.x == 0) { rv[blockIdx.x] = bv; ri[blockIdx.x] = bi; }
 }
 
-// Set-up of pivot B (reference lp_simplex_tableau.cc:10-44 on the tableau after A): row fold,
-// scalars, col'_B, the pivot row after A gathered with A's step applied on the fly, row'_B,
-// the objective row, the list of columns either step touches, the pricing partials of the
-// iteration after B.  st->e/r/d keep describing A until the update kernel has used them.
-__global__ __launch_bounds__(kPartialThreads) void k_pair_finalize(
-    Tab T, Shape sh, PivotState* __restrict__ st, PairInfo* __restrict__ pair,
+// Set-up of step j (reference lp_simplex_tableau.cc:10-44 on the tableau after step j-1): row
+// fold, scalars, col'_j, the pivot row gathered with steps 0..j-1 applied on the fly, row'_j,
+// the objective row, the list of columns any step so far touches (lists of successive steps
+// alternate between two buffers), the pricing partials of the iteration after this step.
+// PivotState keeps describing pivot 0 until the update kernel has used it.
+__global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
+    Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
     const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
-    const double* __restrict__ colp, const double* __restrict__ rowp, const double* __restrict__ colv,
-    double* __restrict__ colp2, double* __restrict__ rowp2, double* __restrict__ obj,
-    const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis, int32_t* __restrict__ active2,
-    int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
+    double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, const double* __restrict__ colv,
+    double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
+    int32_t* __restrict__ lists, int64_t* __restrict__ trace, int64_t trace_cap,
+    double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
-  const int64_t e2 = pair->e2;
+  if (j > 1 && !steps[j - 1].done) return;
+  const int64_t e2 = steps[j].e;
   if (e2 < 0) return;
   double best;
   int64_t r2;
   fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2, s_v, s_i);
-  if (r2 < 0) return;   // unbounded after A: found again, and reported, by the next iteration
-  const double ce2 = pair->ce2;
+  if (r2 < 0) return;   // unbounded after step j-1: found again, and reported, by the next iteration
+  const double ce2 = steps[j].ce;
   const double a2 = colv[r2];
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
   if ((int)blockIdx.x < n_row_blocks) {
+    double* __restrict__ cj = colp + j * sh.lda;
     for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads)
-      colp2[i] = (i == r2) ? __dadd_rn(1.0, a2) : colv[i];
+      cj[i] = (i == r2) ? __dadd_rn(1.0, a2) : colv[i];
     return;
   }
   const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
   const int ncl = sh.nloc + 1;
-  const int64_t e1 = st->e, d1 = st->d, r1 = st->r;
-  const int64_t d2 = (r2 == r1) ? e1 : basis[r2];   // basis[r1] is flipped by the update kernel
   auto local_id = [&](int64_t g) -> int {
     if (g < 0 || g == sh.N) return -1;
     const int64_t o = ordinal_of(g, sh.N);
     return (o % sh.world == sh.rank) ? (int)(o / sh.world) : -1;
   };
-  const int l_e1 = local_id(e1), l_d1 = local_id(d1), l_e2 = local_id(e2), l_d2 = local_id(d2);
-  const double c1r = colp[r2];   // col'_A[r2]
+  // entering / leaving columns of steps 0..j-1 and the basic variable of row r2 after them
+  int l_in[kMaxChain], l_out[kMaxChain];
+  double c_r[kMaxChain - 1];       // col'_s[r2]
+  int64_t d2 = basis[r2];          // basis[] is flipped by the update kernel
+#pragma unroll
+  for (int s = 0; s < kMaxChain - 1; s++) {
+    l_in[s] = l_out[s] = -1;
+    c_r[s] = 0.0;
+    if (s < j) {
+      const int64_t es = s == 0 ? st->e : steps[s].e, ds = s == 0 ? st->d : steps[s].d, rs = s == 0 ? st->r : steps[s].r;
+      l_in[s] = local_id(es);
+      l_out[s] = local_id(ds);
+      c_r[s] = colp[s * sh.lda + r2];
+      if (rs == r2) d2 = es;
+    }
+  }
+  const int l_e2 = local_id(e2), l_d2 = local_id(d2);
+  int32_t* __restrict__ list = lists + (size_t)(j & 1) * ncl;
   double nbv = -DBL_MAX;
   int64_t nbi = -1;
   for (int l0 = cb * kPartialThreads; l0 < ncl; l0 += n_cb * kPartialThreads) {
@@ -748,18 +790,23 @@ __global__ __launch_bounds__(kPartialThreads) void k_pair_finalize(
     bool act = false, second = false;
     if (l < ncl) {
       double t = T.col(l)[r2];
-      const double r1j = rowp[l];
-      if (r1j != 0.0) t = flushz(__dadd_rn(t, __dmul_rn(c1r, r1j)));
+      bool basic = l < sh.nloc && is_basic[l] != 0;
+#pragma unroll
+      for (int s = 0; s < kMaxChain - 1; s++) {
+        if (s < j) {
+          const double rs = rowp[s * rstride + l];
+          if (rs != 0.0) { t = flushz(__dadd_rn(t, __dmul_rn(c_r[s], rs))); act = true; }
+          if (l == l_in[s]) basic = true; else if (l == l_out[s]) basic = false;
+        }
+      }
       const double rp2 = __dmul_rn(t, f2);
       double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g2)));
       if (l == l_e2) o = 0.0;
       obj[l] = o;
-      rowp2[l] = rp2;
+      rowp[j * rstride + l] = rp2;
       second = rp2 != 0.0;
-      act = second || r1j != 0.0;
+      act = act || second;
       if (l < sh.nloc) {
-        bool basic = is_basic[l] != 0;
-        if (l == l_e1) basic = true; else if (l == l_d1) basic = false;
         if (l == l_e2) basic = true; else if (l == l_d2) basic = false;
         if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
       }
@@ -771,37 +818,38 @@ __global__ __launch_bounds__(kPartialThreads) void k_pair_finalize(
       const int leader = __ffsll((long long)mask) - 1;
       int base = 0;
       if (lane == leader) {
-        base = atomicAdd(&st->n_active2, __popcll(mask));
-        if (mask2) atomicAdd(&pair->n_second, __popcll(mask2));
+        base = atomicAdd(&steps[j].n_list, __popcll(mask));
+        if (mask2) atomicAdd(&steps[j].n_touched, __popcll(mask2));
       }
       base = __shfl(base, leader, kWave);
-      if (act) active2[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+      if (act) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
     }
   }
   block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
   if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
   if (cb == 0 && threadIdx.x == 0) {
-    pair->r2 = r2; pair->d2 = d2; pair->a2 = a2; pair->f2 = f2; pair->g2 = g2;
-    pair->have2 = 1;
+    steps[j].r = r2; steps[j].d = d2; steps[j].a = a2; steps[j].f = f2; steps[j].g = g2;
+    steps[j].done = 1;
     const int64_t it = st->iter;
     if (it < trace_cap) { trace[2 * it] = e2; trace[2 * it + 1] = r2; }
     st->iter = it + 1;
   }
 }
 
-// The pass itself: A alone over A's list, or both steps over the union list.
+// The pass itself: pivot 0 alone over its own list, or the whole chain over the list of its last step.
 template <int kUnroll, bool kNT>
-__global__ __launch_bounds__(kUpdateThreads, 2) void k_update_pair(
-    Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, const int32_t* __restrict__ active,
-    const double* __restrict__ colp2, const double* __restrict__ rowp2, const int32_t* __restrict__ active2,
-    PivotState* __restrict__ st, const PairInfo* __restrict__ pair, Shape sh,
+__global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
+    Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
+    const int32_t* __restrict__ active, const int32_t* __restrict__ lists, int depth,
+    PivotState* __restrict__ st, const ChainStep* __restrict__ steps, Shape sh,
     uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
   if (st->status != ST_RUNNING) return;
-  const bool two = pair->have2 != 0;
-  const int n_list = two ? st->n_active2 : st->n_active;
-  const int32_t* __restrict__ list = two ? active2 : active;
+  int n_steps = 1;
+  while (n_steps < depth && steps[n_steps].done) n_steps++;
+  const int n_list = n_steps > 1 ? steps[n_steps - 1].n_list : st->n_active;
+  const int32_t* __restrict__ list = n_steps > 1 ? lists + (size_t)((n_steps - 1) & 1) * (sh.nloc + 1) : active;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // bookkeeping of reference lp_simplex_tableau.cc:16-28, A then B
+    // bookkeeping of reference lp_simplex_tableau.cc:16-28, pivot after pivot
     auto flip = [&](int64_t e, int64_t d, int64_t r) {
       const int64_t eo = ordinal_of(e, sh.N);
       if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
@@ -812,20 +860,19 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_pair(
       basis[r] = e;
     };
     flip(st->e, st->d, st->r);
-    if (two) {
-      flip(pair->e2, pair->d2, pair->r2);
-      st->e = pair->e2; st->r = pair->r2; st->d = pair->d2;   // no other workgroup of this launch reads these
-      st->a = pair->a2; st->ce = pair->ce2; st->f = pair->f2; st->g = pair->g2;
+    for (int s = 1; s < n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
+    if (n_steps > 1) {   // no other workgroup of this launch reads these fields
+      const ChainStep& z = steps[n_steps - 1];
+      st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
     }
   }
   const int n_vec = (int)(lda / 2);
-  const double2* __restrict__ cp1 = reinterpret_cast<const double2*>(colp);
-  const double2* __restrict__ cp2 = reinterpret_cast<const double2*>(colp2);
+  const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
   for (int k = blockIdx.x; k < n_list; k += gridDim.x) {
     const int l = list[k];
-    const double r1 = rowp[l];
-    const double r2 = two ? rowp2[l] : 0.0;
-    const bool s1 = r1 != 0.0, s2 = r2 != 0.0;   // uniform over the workgroup
+    double rs[kMaxChain];   // uniform over the workgroup
+#pragma unroll
+    for (int s = 0; s < kMaxChain; s++) rs[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
     double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l));
     int v = threadIdx.x;
     for (; v + (kUnroll - 1) * kUpdateThreads < n_vec; v += kUnroll * kUpdateThreads) {
@@ -834,17 +881,119 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_pair(
       for (int u = 0; u < kUnroll; u++) t[u] = ld16<kNT>(p + v + u * kUpdateThreads);
       __builtin_amdgcn_sched_barrier(0);   // all loads of the batch before its first store
 #pragma unroll
-      for (int u = 0; u < kUnroll; u++) {
-        if (s1) t[u] = rank1(t[u], cp1[v + u * kUpdateThreads], r1);
-        if (s2) t[u] = rank1(t[u], cp2[v + u * kUpdateThreads], r2);
-        st16<kNT>(p + v + u * kUpdateThreads, t[u]);
+      for (int s = 0; s < kMaxChain; s++) {
+        if (rs[s] != 0.0) {
+#pragma unroll
+          for (int u = 0; u < kUnroll; u++) t[u] = rank1(t[u], cp[s * n_vec + v + u * kUpdateThreads], rs[s]);
+        }
       }
+#pragma unroll
+      for (int u = 0; u < kUnroll; u++) st16<kNT>(p + v + u * kUpdateThreads, t[u]);
     }
     for (; v < n_vec; v += kUpdateThreads) {
       double2 o = ld16<kNT>(p + v);
-      if (s1) o = rank1(o, cp1[v], r1);
-      if (s2) o = rank1(o, cp2[v], r2);
+#pragma unroll
+      for (int s = 0; s < kMaxChain; s++)
+        if (rs[s] != 0.0) o = rank1(o, cp[s * n_vec + v], rs[s]);
       st16<kNT>(p + v, o);
+    }
+  }
+}
+
+// The same pass with the col' vectors in REGISTERS.  k_update_chain re-reads every col'_s per
+// column from L2 (8 bytes per entry and step next to the 16 bytes of HBM traffic), which limits a
+// long chain.  Here a workgroup owns a slab of 512*kR rows, keeps its kK slices of col' in
+// registers and walks the column list, kC columns (kR*kC 16-byte loads per lane) in flight; row'
+// values are uniform per column.  Fast path: full chain and every step touches all kC columns (no
+// branches inside); anything else (shorter chain, a column some step leaves alone, the tail of the
+// list) takes the per-step tests of k_update_chain.  Needs lda % (512*kR) == 0.
+template <int kK, int kR, int kC, bool kNT>
+__global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
+    Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
+    const int32_t* __restrict__ active, const int32_t* __restrict__ lists, int depth,
+    PivotState* __restrict__ st, const ChainStep* __restrict__ steps, Shape sh,
+    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis, int n_slabs) {
+  if (st->status != ST_RUNNING) return;
+  int n_steps = 1;
+  while (n_steps < depth && steps[n_steps].done) n_steps++;
+  const int n_list = n_steps > 1 ? steps[n_steps - 1].n_list : st->n_active;
+  const int32_t* __restrict__ list = n_steps > 1 ? lists + (size_t)((n_steps - 1) & 1) * (sh.nloc + 1) : active;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    auto flip = [&](int64_t e, int64_t d, int64_t r) {
+      const int64_t eo = ordinal_of(e, sh.N);
+      if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+      if (d >= 0 && d != sh.N) {
+        const int64_t dord = ordinal_of(d, sh.N);
+        if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+      }
+      basis[r] = e;
+    };
+    flip(st->e, st->d, st->r);
+    for (int s = 1; s < n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
+    if (n_steps > 1) {
+      const ChainStep& z = steps[n_steps - 1];
+      st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
+    }
+  }
+  const int n_vec = (int)(lda / 2);
+  const int slab = blockIdx.x % n_slabs, grp = blockIdx.x / n_slabs, n_grp = gridDim.x / n_slabs;
+  const int v0 = slab * (kUpdateThreads * kR) + threadIdx.x;
+  const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
+  double2 c[kK][kR];
+#pragma unroll
+  for (int s = 0; s < kK; s++)
+#pragma unroll
+    for (int r = 0; r < kR; r++) {
+      c[s][r].x = c[s][r].y = 0.0;
+      if (s < n_steps) c[s][r] = cp[s * n_vec + v0 + r * kUpdateThreads];
+    }
+  for (int k0 = grp * kC; k0 < n_list; k0 += n_grp * kC) {
+    double2* p[kC];
+    double rs[kC][kK];
+    bool fast = n_steps == kK && k0 + kC <= n_list;
+#pragma unroll
+    for (int u = 0; u < kC; u++) {
+      const bool valid = k0 + u < n_list;
+      const int l = valid ? list[k0 + u] : 0;
+      p[u] = valid ? reinterpret_cast<double2*>(T.col(l)) + v0 : nullptr;
+#pragma unroll
+      for (int s = 0; s < kK; s++) {
+        rs[u][s] = (valid && s < n_steps) ? rowp[s * rstride + l] : 0.0;
+        fast = fast && rs[u][s] != 0.0;
+      }
+    }
+    double2 t[kC][kR];
+    if (fast) {
+#pragma unroll
+      for (int u = 0; u < kC; u++)
+#pragma unroll
+        for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);
+      __builtin_amdgcn_sched_barrier(0);   // all loads of the batch before its first store
+#pragma unroll
+      for (int u = 0; u < kC; u++) {
+#pragma unroll
+        for (int s = 0; s < kK; s++)
+#pragma unroll
+          for (int r = 0; r < kR; r++) t[u][r] = rank1(t[u][r], c[s][r], rs[u][s]);
+#pragma unroll
+        for (int r = 0; r < kR; r++) st16<kNT>(p[u] + r * kUpdateThreads, t[u][r]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < kC; u++) {
+        if (p[u] == nullptr) continue;
+#pragma unroll
+        for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);
+#pragma unroll
+        for (int s = 0; s < kK; s++) {
+          if (rs[u][s] != 0.0) {
+#pragma unroll
+            for (int r = 0; r < kR; r++) t[u][r] = rank1(t[u][r], c[s][r], rs[u][s]);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < kR; r++) st16<kNT>(p[u] + r * kUpdateThreads, t[u][r]);
+      }
     }
   }
 }

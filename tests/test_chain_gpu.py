@@ -1,5 +1,5 @@
-"""GPU parity of the loop that applies two MAX_COST pivots per pass over the tableau
-(k_pair_ratio / k_pair_finalize / k_update_pair), forced on inputs the oracle solves fully:
+"""GPU parity of the loop that applies a chain of MAX_COST pivots per pass over the tableau
+(k_chain_ratio / k_chain_finalize / k_update_chain), forced on inputs the oracle solves fully:
 trace, tableau, objective row and basis flags must be bit-identical to one pivot per pass."""
 import numpy as np
 import pytest
@@ -12,13 +12,14 @@ from test_engine_parity import _random_tied_lp, assert_same_tableau, bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _pair_loop(monkeypatch):
-    monkeypatch.setenv("LPAMD_PAIR", "1")
+@pytest.fixture(autouse=True, params=[2, 3, 8])
+def depth(request, monkeypatch):
+    monkeypatch.setenv("LPAMD_CHAIN", str(request.param))
+    return request.param
 
 
 @pytest.mark.parametrize("name", sorted({n for n, s in all_cases() if s == "max_cost"}))
-def test_goldens_two_pivots_per_pass(lpamd, name):
+def test_goldens_chained_pivots(lpamd, name):
     tab, dt = lo.from_text(case_text(name))
     want = dt.solve(lo.MAX_COST)
     eng = lpamd.TableauEngine(tab.m, tab.N)
@@ -35,7 +36,7 @@ def test_goldens_two_pivots_per_pass(lpamd, name):
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_lps_with_ties_two_pivots_per_pass(lpamd, seed):
+def test_random_lps_with_ties_chained_pivots(lpamd, seed):
     rng = np.random.default_rng(seed)
     text = _random_tied_lp(rng, int(rng.integers(3, 12)), int(rng.integers(2, 10)))
     tab, dt = lo.from_text(text)
@@ -49,15 +50,14 @@ def test_random_lps_with_ties_two_pivots_per_pass(lpamd, seed):
     eng.close()
 
 
-def test_budgets_odd_even_and_continuation(lpamd):
-    """A budget that ends after the first pivot of a pass, after the second, and runs that go on
-    from either state; then to the optimum."""
+def test_budgets_and_continuation(lpamd, depth):
+    """Budgets that end at every position of a chain, and runs that go on from there; then to the optimum."""
     m, n = 600, 1100
     dt = lo.DenseTableau.synthetic(m, n, 7)
     eng = lpamd.TableauEngine(m, n + m)
     eng.fill_synthetic(n, 7)
     total = 0
-    for k in (1, 2, 37, 1, 1, 4, 3):
+    for k in (1, 2, 37, 1, 1, 4, 3, 8, 9, 16):
         res, done = eng.run_pivots(lpamd.MAX_COST, k)
         total += k
         assert (res, done) == (lpamd.LIMIT, k)
@@ -66,7 +66,7 @@ def test_budgets_odd_even_and_continuation(lpamd):
         assert eng.trace() == dt.trace()
         assert_same_tableau(eng, dt)
         pivots, streamed, touched = eng.pass_stats()
-        assert pivots == (1 if k % 2 else 2) and streamed <= touched <= 2 * streamed
+        assert pivots == (k - 1) % depth + 1 and streamed <= touched <= pivots * streamed
     res, done = eng.run_pivots(lpamd.MAX_REDUCTION, 5)     # the other strategy in between
     assert (res, done) == (lpamd.LIMIT, 5)
     assert dt.solve(lo.MAX_REDUCTION, max_pivots=total + 5) == lo.LIMIT
@@ -79,7 +79,7 @@ def test_budgets_odd_even_and_continuation(lpamd):
 
 
 @pytest.mark.parametrize("m,n", [(1, 1), (1, 5), (3, 1), (511, 2), (512, 3), (513, 3), (2, 700), (2500, 40)])
-def test_extreme_shapes_two_pivots_per_pass(lpamd, m, n):
+def test_extreme_shapes_chained_pivots(lpamd, m, n):
     dt = lo.DenseTableau.synthetic(m, n, 2)
     eng = lpamd.TableauEngine(m, n + m)
     eng.fill_synthetic(n, 2)
@@ -90,7 +90,7 @@ def test_extreme_shapes_two_pivots_per_pass(lpamd, m, n):
     eng.close()
 
 
-def test_unbounded_found_by_the_second_pivot_of_a_pass(lpamd):
+def test_unbounded_found_inside_a_chain(lpamd):
     # after x1 enters (row 0), x2 has no eligible row: the pass applies the first pivot alone
     tab, dt = lo.from_text("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n")
     eng = lpamd.TableauEngine(tab.m, tab.N)
@@ -101,20 +101,22 @@ def test_unbounded_found_by_the_second_pivot_of_a_pass(lpamd):
     eng.close()
 
 
-def test_default_loop_pairs_long_columns(lpamd, monkeypatch):
-    """m > 2048 on one GPU takes the paired loop by default; LPAMD_PAIR=0 gives the same bits."""
+def test_default_loop_chains_long_columns(lpamd, monkeypatch, depth):
+    """m > 2048 on one GPU chains pivots by default; LPAMD_CHAIN=1 gives the same bits."""
+    if depth != 2:
+        pytest.skip("one run is enough")
     m, n, k = 2304, 1500, 41
-    monkeypatch.delenv("LPAMD_PAIR")
+    monkeypatch.delenv("LPAMD_CHAIN")
     a = lpamd.TableauEngine(m, n + m)
     a.fill_synthetic(n, 5)
     assert a.run_pivots(lpamd.MAX_COST, k) == (lpamd.LIMIT, k)
-    assert a.pass_stats()[0] == 1          # 41st pivot alone in the last pass
-    assert a.run_pivots(lpamd.MAX_COST, k + 1) == (lpamd.LIMIT, k + 1)
-    assert a.pass_stats()[0] == 2
-    monkeypatch.setenv("LPAMD_PAIR", "0")
+    assert a.pass_stats()[0] == 1          # 41 = 5 passes of 8 + 1
+    assert a.run_pivots(lpamd.MAX_COST, k + 3) == (lpamd.LIMIT, k + 3)
+    assert a.pass_stats()[0] == 4          # 44 = 5 passes of 8 + 4
+    monkeypatch.setenv("LPAMD_CHAIN", "1")
     b = lpamd.TableauEngine(m, n + m)
     b.fill_synthetic(n, 5)
-    assert b.run_pivots(lpamd.MAX_COST, 2 * k + 1) == (lpamd.LIMIT, 2 * k + 1)
+    assert b.run_pivots(lpamd.MAX_COST, 2 * k + 3) == (lpamd.LIMIT, 2 * k + 3)
     assert b.pass_stats()[0] == 1
     assert a.trace() == b.trace()
     ta, tb = a.download(), b.download()
@@ -122,8 +124,31 @@ def test_default_loop_pairs_long_columns(lpamd, monkeypatch):
         assert np.array_equal(bits(x), bits(y))
     assert np.array_equal(ta[2], tb[2])
     dt = lo.DenseTableau.synthetic(m, n, 5)
-    assert dt.solve(lo.MAX_COST, max_pivots=2 * k + 1) == lo.LIMIT
+    assert dt.solve(lo.MAX_COST, max_pivots=2 * k + 3) == lo.LIMIT
     assert a.trace() == dt.trace()
     assert_same_tableau(a, dt)
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("slab", [1, 2, 3, 4])
+@pytest.mark.parametrize("chain,nt", [(4, "0"), (8, "1")])
+def test_slab_pass_with_col_in_registers(lpamd, monkeypatch, depth, slab, chain, nt):
+    """k_update_slab (col' slices in registers, a workgroup per row slab) against the oracle: full
+    solve, so short chains at the end, columns a step leaves alone and list tails all occur."""
+    if depth != 2:
+        pytest.skip("one run is enough")
+    monkeypatch.setenv("LPAMD_CHAIN", str(chain))
+    monkeypatch.setenv("LPAMD_SLAB", str(slab))
+    monkeypatch.setenv("LPAMD_UPDATE_NT", nt)
+    monkeypatch.setenv("LPAMD_SLAB_GRID", "24")
+    m, n, seed = 2000, 900, 11
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    want = dt.solve(lo.MAX_COST)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    res, npiv = eng.solve(lpamd.MAX_COST)
+    assert res == want == lpamd.SOLVED and npiv == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()

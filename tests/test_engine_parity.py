@@ -162,11 +162,11 @@ def test_extreme_shapes(lpamd, m, n):
     {"LPAMD_UPDATE_UNROLL": "4", "LPAMD_UPDATE_GRID": "7"},
     {"LPAMD_PLACEMENT": "0"},
     {"LPAMD_TWO_LAUNCH": "0"},
-    {"LPAMD_TWO_LAUNCH": "0", "LPAMD_PAIR": "0"},
+    {"LPAMD_TWO_LAUNCH": "0", "LPAMD_CHAIN": "1"},
     {"LPAMD_TWO_LAUNCH": "1", "LPAMD_UPDATE_UNROLL": "2"},
-    {"LPAMD_PAIR": "1"},
-    {"LPAMD_PAIR": "1", "LPAMD_UPDATE_NT": "1", "LPAMD_UPDATE_UNROLL": "2"},
-    {"LPAMD_PAIR": "1", "LPAMD_UPDATE_NT": "0", "LPAMD_UPDATE_GRID": "7"},
+    {"LPAMD_CHAIN": "2"},
+    {"LPAMD_CHAIN": "8", "LPAMD_UPDATE_NT": "1", "LPAMD_UPDATE_UNROLL": "2"},
+    {"LPAMD_CHAIN": "3", "LPAMD_UPDATE_NT": "0", "LPAMD_UPDATE_GRID": "7"},
 ])
 @pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
 def test_update_kernel_variants_are_bit_identical(lpamd, monkeypatch, knobs, strategy):
