@@ -42,7 +42,7 @@ DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
 
-def pmc_traffic(config, world):
+def pmc_traffic(config, world, pivots_per_launch=1):
     """HBM bytes per k_update launch from the committed rocprofv3 PMC passes of this
     same command (profiles/*/pmc_hbm_traffic_*.json: FETCH_SIZE doubled as gfx950
     requires, plus WRITE_SIZE).  None when no pass exists for the configuration."""
@@ -55,7 +55,7 @@ def pmc_traffic(config, world):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("config") == config:
+        if d.get("config") == config and d.get("pivots_per_launch", 1) == pivots_per_launch:
             best = d.get("traffic_bytes_per_launch")
     return best
 
@@ -166,6 +166,7 @@ def main():
     sync_all()
     el = time.perf_counter() - t0
     upd_ms, launches, active = eng.update_stats()
+    pass_pivots, pass_streamed, _ = eng.pass_stats()
     eng.set_profiling(False)
     assert done == K and res == lp.LIMIT, "timed region ended early: result %d after %d pivots" % (res, done)
     if use_dist:
@@ -174,7 +175,11 @@ def main():
         el = float(t.item())
 
     avg_ms = upd_ms / max(launches, 1)
-    algo_bytes = 16.0 * m * active          # every entry of an active local column is read once and written once
+    # algorithmic bytes: every entry of an active local column is read once and written once PER PIVOT
+    # (16*m*n_active); a pass that applies a chain of pivots counts the columns of each of them
+    # (`active`), while it streams the tableau only once (`pass_streamed` columns)
+    algo_bytes = 16.0 * m * active
+    streamed_bytes = 16.0 * m * pass_streamed
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
     if use_dist:
         t = torch.tensor([achieved], dtype=torch.float64, device=dev)
@@ -200,9 +205,15 @@ def main():
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, world),
-                     "kernel": "k_update", "avg_launch_ms": round(avg_ms, 5), "launches": int(launches),
-                     "algorithmic_bytes_per_launch": algo_bytes, "active_columns": int(active)},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, world, pass_pivots),
+                     "kernel": "k_update_slab" if pass_pivots > 1 else "k_update", "avg_launch_ms": round(avg_ms, 5),
+                     "launches": int(launches), "algorithmic_bytes_per_launch": algo_bytes, "active_columns": int(active),
+                     "pivots_per_launch": int(pass_pivots), "streamed_columns": int(pass_streamed),
+                     "streamed_bytes_per_launch": streamed_bytes,
+                     "streamed_GBps": round(streamed_bytes / (avg_ms * 1e-3) / 1e9, 1) if launches else 0.0,
+                     "note": "achieved = algorithmic bytes (16*m*n_active per pivot x pivots per launch) / launch time; a launch "
+                             "applies a chain of pivots in ONE pass over the tableau, so the HBM traffic of a launch is "
+                             "streamed_bytes_per_launch (PMC: traffic) and achieved may exceed the HBM peak"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

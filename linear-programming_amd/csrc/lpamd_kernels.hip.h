@@ -662,7 +662,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
 // is used up, at the optimum or when a column has no eligible row; the pass then applies
 // what has been set up and the next iteration of the loop reports the outcome exactly as
 // the one-pivot loop does.  Step s keeps col'_s at colp + s*lda and row'_s at rowp + s*rstride.
-constexpr int kMaxChain = 8;
+constexpr int kMaxChain = 16;
 
 struct ChainStep {   // pivots 1.. of the pass (pivot 0 is described by PivotState)
   int32_t done;      // 1 once k_chain_finalize has set the step up

@@ -5,7 +5,7 @@ out=gpurun_out/slab_sweep.jsonl
 : > $out
 cfg=${1:-synthetic_m32768_n65536}
 steps=${2:-96}
-for d in 4 8; do
+for d in ${3:-4 8}; do
   for sl in 0 1 2 3 4; do
     LPAMD_CHAIN=$d LPAMD_SLAB=$sl timeout -k 10 120 python -u bench.py --config $cfg --steps $steps --warmup 8 --no-cpu-baseline | sed "s/^{/{\"chain\": $d, \"slab\": $sl, /" >> $out
   done

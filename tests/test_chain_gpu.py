@@ -12,7 +12,7 @@ from test_engine_parity import _random_tied_lp, assert_same_tableau, bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 3, 8])
+@pytest.fixture(autouse=True, params=[2, 3, 8, 16])
 def depth(request, monkeypatch):
     monkeypatch.setenv("LPAMD_CHAIN", str(request.param))
     return request.param
@@ -57,7 +57,7 @@ def test_budgets_and_continuation(lpamd, depth):
     eng = lpamd.TableauEngine(m, n + m)
     eng.fill_synthetic(n, 7)
     total = 0
-    for k in (1, 2, 37, 1, 1, 4, 3, 8, 9, 16):
+    for k in (1, 2, 37, 1, 1, 4, 3, 8, 9, 16, 17):
         res, done = eng.run_pivots(lpamd.MAX_COST, k)
         total += k
         assert (res, done) == (lpamd.LIMIT, k)
@@ -132,7 +132,7 @@ def test_default_loop_chains_long_columns(lpamd, monkeypatch, depth):
 
 
 @pytest.mark.parametrize("slab", [1, 2, 3, 4])
-@pytest.mark.parametrize("chain,nt", [(4, "0"), (8, "1")])
+@pytest.mark.parametrize("chain,nt", [(4, "0"), (8, "1"), (16, "0")])
 def test_slab_pass_with_col_in_registers(lpamd, monkeypatch, depth, slab, chain, nt):
     """k_update_slab (col' slices in registers, a workgroup per row slab) against the oracle: full
     solve, so short chains at the end, columns a step leaves alone and list tails all occur."""
