@@ -432,6 +432,8 @@ bool launch_slab_shape(lpamd_engine* e) {
 bool launch_update_slab(lpamd_engine* e) {
   if (e->chain_depth == 4) return launch_slab_shape<4>(e);
   if (e->chain_depth == 8) return launch_slab_shape<8>(e);
+  if (e->chain_depth == 10) return launch_slab_shape<10>(e);
+  if (e->chain_depth == 12) return launch_slab_shape<12>(e);
   if (e->chain_depth == 16) return launch_slab_shape<16>(e);
   return false;
 }
