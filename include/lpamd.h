@@ -187,6 +187,17 @@ int lpamd_lookahead_export(lpamd_engine* eng, void* cand_dev, void* xlocal_dev);
 int lpamd_lookahead_update(lpamd_engine* eng);
 int lpamd_lookahead_select(lpamd_engine* eng, const void* cands_dev, int32_t world, const void* xlocal_dev, void* xbuf_dev,
                            void* hip_stream);
+/* Several pivots per pass over column shards (MAX_COST; same arithmetic as reference
+ * lp_simplex_tableau.cc:10-52 and 188-227 pivot by pivot, same results).  After step a has set a
+ * pivot up, the next one can be set up as well before any rank-1 update has run: step b exports
+ * the next local candidate as ALL pivots set up so far will leave it, step d delivers the winner
+ * (this time the engine's stream waits for it), and lpamd_chain_step runs the ratio test on the
+ * delivered column and sets that pivot up too.  Up to lpamd_chain_depth pivots (step a included)
+ * may be set up this way; step c then applies all of them in ONE pass over the shard.  A chain
+ * that cannot go on (budget, optimum, no eligible row) turns the remaining lpamd_chain_step calls
+ * into no-ops and the next step a reports the outcome. */
+int lpamd_chain_depth(const lpamd_engine* eng, int32_t* depth);
+int lpamd_chain_step(lpamd_engine* eng, void* xbuf_dev);
 /* Pivot budget of the step-wise loop: after max_pivots more pivots (< 0: no limit)
  * the device steps turn into no-ops.  Also re-arms a loop that hit its budget.
  * lpamd_poll reports LPAMD_LIMIT both while running and when the budget is

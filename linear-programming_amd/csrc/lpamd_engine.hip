@@ -97,6 +97,7 @@ struct lpamd_engine {
   uint8_t* cand_next = nullptr; // pricing candidates after the pivot being applied
   Candidate* cand = nullptr;
   Candidate* cand_la = nullptr;   // look-ahead exchange: winner of the next pivot, written on the exchange stream
+  int32_t pending_steps = 0;      // pivots set up and waiting for the pass (lpamd_lookahead_setup + lpamd_chain_step calls)
   bool update_pending = false;    // a pivot has been set up (k_pivot_finalize) and its rank-1 update is not enqueued yet
   double* part_v = nullptr;     // [2 * kMaxPartials]: pricing partials, then ratio partials
   int64_t* part_i = nullptr;
@@ -438,20 +439,36 @@ bool launch_update_slab(lpamd_engine* e) {
   return false;
 }
 
-// The further pivots of a pass (per step: pricing fold + rebuilt column + ratio partials, then set-up) and
-// the pass itself, for the pivot that k_pivot_finalize has just set up.
-int enqueue_chain_tail(lpamd_engine* e, int depth) {
+// Step j >= 1 of a chain: ratio partials (pricing fold + rebuilt column on one GPU; candidate record + column
+// from the exchange over column shards), then the set-up.
+int enqueue_chain_step(lpamd_engine* e, int j, const Candidate* xcand, double* xcol) {
   double* rv = e->part_v + kMaxPartials;
   int64_t* ri = e->part_i + kMaxPartials;
-  for (int j = 1; j < depth; j++) {
-    hipLaunchKernelGGL(k_chain_ratio, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
-                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->colv, rv, ri);
-    LP_TRY(check_launch("k_chain_ratio"));
-    hipLaunchKernelGGL(k_chain_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
-                       e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->colv, e->obj, e->is_basic,
-                       e->basis, e->lists, e->trace, e->trace_cap, e->part_v, e->part_i);
-    LP_TRY(check_launch("k_chain_finalize"));
-  }
+  double* colv = xcol ? xcol : e->colv;
+  if (xcol)
+    hipLaunchKernelGGL(k_chain_ratio<true>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
+                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, colv, rv, ri, xcand);
+  else
+    hipLaunchKernelGGL(k_chain_ratio<false>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
+                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, colv, rv, ri, xcand);
+  LP_TRY(check_launch("k_chain_ratio"));
+  hipLaunchKernelGGL(k_chain_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
+                     e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, colv, e->obj, e->is_basic,
+                     e->basis, e->lists, e->trace, e->trace_cap, e->part_v, e->part_i);
+  LP_TRY(check_launch("k_chain_finalize"));
+  e->price_partials_fresh = true;
+  return LPAMD_OK;
+}
+
+int enqueue_chain_update(lpamd_engine* e);
+
+// The further pivots of a pass and the pass itself, for the pivot that k_pivot_finalize has just set up.
+int enqueue_chain_tail(lpamd_engine* e, int depth) {
+  for (int j = 1; j < depth; j++) LP_TRY(enqueue_chain_step(e, j, nullptr, nullptr));
+  return enqueue_chain_update(e);
+}
+
+int enqueue_chain_update(lpamd_engine* e) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->ev_used + 2 > e->ev.size()) {
@@ -661,9 +678,10 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->two_launch = world == 1 && m <= 2048;
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
   // Longer columns: a pivot is bound by the HBM pass, so a chain of pivots shares one (see k_update_chain)
-  e->chain_depth = (world == 1 && !e->two_launch) ? 8 : 1;
+  // (column shards chain through lpamd_chain_step, the caller runs the exchange of every step)
+  e->chain_depth = !e->two_launch ? 8 : 1;
   if (const char* env = getenv("LPAMD_CHAIN")) {
-    e->chain_depth = world == 1 ? std::max(1, std::min(kMaxChain, atoi(env))) : 1;
+    e->chain_depth = std::max(1, std::min(kMaxChain, atoi(env)));
     if (e->chain_depth > 1) e->two_launch = false;
   }
   // Measured (scripts/slab_sweep.sh, m=32768 n=65536, chain of 8): col' from L2 8.44 ms per pass; in registers with
@@ -1297,7 +1315,8 @@ int lpamd_lookahead_export(lpamd_engine* e, void* cand_dev, void* xlocal_dev) {
   if (!cand_dev || !xlocal_dev) return set_err(LPAMD_E_ARG, "lookahead_export: null buffer");
   LP_TRY(enqueue_pricing(e, LPAMD_MAX_COST, (Candidate*)cand_dev));
   hipLaunchKernelGGL(k_export_lookahead, dim3((unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->sh, e->st,
-                     (const Candidate*)cand_dev, e->colp, e->rowp, e->update_pending ? 1 : 0, (double*)xlocal_dev);
+                     (const Candidate*)cand_dev, e->colp, e->rowp, e->rstride, e->steps, e->update_pending ? e->pending_steps : 0,
+                     (double*)xlocal_dev);
   return check_launch("k_export_lookahead");
 }
 
@@ -1320,6 +1339,26 @@ int lpamd_lookahead_setup(lpamd_engine* e, const void* xbuf_dev) {
   LP_TRY(enqueue_ratio_partial(e, false, e->cand_la, (const double*)xbuf_dev));
   LP_TRY(enqueue_finalize(e, true, e->cand_la, (const double*)xbuf_dev, -1));
   e->update_pending = true;
+  e->pending_steps = 1;
+  return LPAMD_OK;
+}
+
+int lpamd_chain_depth(const lpamd_engine* e, int32_t* depth) {
+  if (!e || !depth) return set_err(LPAMD_E_ARG, "chain_depth: null argument");
+  *depth = std::min<int32_t>(e->chain_depth, kMaxChain - 1);
+  return LPAMD_OK;
+}
+
+int lpamd_chain_step(lpamd_engine* e, void* xbuf_dev) {
+  CHECK_LOADED(e);
+  if (!xbuf_dev) return set_err(LPAMD_E_ARG, "chain_step: null exchange buffer");
+  if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain_step: no pivot has been set up by lpamd_lookahead_setup");
+  if (e->pending_steps >= std::min<int32_t>(e->chain_depth, kMaxChain - 1))
+    return set_err(LPAMD_E_STATE, "chain_step: the pass already holds %d pivots", e->pending_steps);
+  e->apply_since_pull++;
+  LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
+  LP_TRY(enqueue_chain_step(e, e->pending_steps, e->cand_la, (double*)xbuf_dev));
+  e->pending_steps++;
   return LPAMD_OK;
 }
 
@@ -1327,6 +1366,10 @@ int lpamd_lookahead_update(lpamd_engine* e) {
   CHECK_LOADED(e);
   if (!e->update_pending) return set_err(LPAMD_E_STATE, "lookahead_update: no pivot has been set up");
   e->update_pending = false;
+  const int steps = e->pending_steps;
+  e->pending_steps = 0;
+  e->loop_depth = steps;
+  if (steps > 1) return enqueue_chain_update(e);
   return enqueue_update(e, false);
 }
 

@@ -684,11 +684,14 @@ __device__ __forceinline__ double chain_apply(double v, int j, const double* __r
 // Step j >= 1: pricing fold on the objective row after step j-1, the entering column and the
 // right-hand side as steps 0..j-1 will leave them (column written to colv, the tableau is not
 // touched) and the ratio-test partials of reference lp_simplex_tableau.cc:207-227 on them.
+// kExternal (column shards): the entering column has been chosen among all ranks and arrives,
+// already rebuilt by its owner, in `colv` together with the candidate record `xcand`.
+template <bool kExternal>
 __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
     const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
     const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
-    double* __restrict__ colv, double* __restrict__ rv, int64_t* __restrict__ ri) {
+    double* __restrict__ colv, double* __restrict__ rv, int64_t* __restrict__ ri, const Candidate* __restrict__ xcand) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
@@ -700,23 +703,34 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
   }
   if (st->iter >= st->max_iter) return;   // the budget ends with step j-1
   double ce;
-  int64_t l;
-  fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
-  if (l < 0) return;                      // optimal after step j-1
-  if (lead) { steps[j].e = gcol_of(l * sh.world + sh.rank, sh.N); steps[j].ce = ce; }
+  int64_t l = 0;
+  if (kExternal) {
+    const int64_t e = xcand->gcol;
+    if (e < 0) return;                    // optimal after step j-1
+    if (lead) { steps[j].e = e; steps[j].ce = xcand->ce; }
+  } else {
+    fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
+    if (l < 0) return;                    // optimal after step j-1
+    if (lead) { steps[j].e = gcol_of(l * sh.world + sh.rank, sh.N); steps[j].ce = ce; }
+  }
   const double* __restrict__ col = T.col(l);
   const double* __restrict__ rhs = T.col(sh.nloc);
   double rs_c[kMaxChain - 1], rs_b[kMaxChain - 1];
 #pragma unroll
   for (int s = 0; s < kMaxChain - 1; s++) {
-    rs_c[s] = s < j ? rowp[s * rstride + l] : 0.0;
+    rs_c[s] = (!kExternal && s < j) ? rowp[s * rstride + l] : 0.0;
     rs_b[s] = s < j ? rowp[s * rstride + sh.nloc] : 0.0;
   }
   double bv = DBL_MAX;
   int64_t bi = -1;
   for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
-    const double a = chain_apply(col[i], j, colp, sh.lda, i, rs_c);
-    colv[i] = a;
+    double a;
+    if (kExternal) {
+      a = colv[i];
+    } else {
+      a = chain_apply(col[i], j, colp, sh.lda, i, rs_c);
+      colv[i] = a;
+    }
     if ((float)a > -1e-6f) continue;
     const double b = chain_apply(rhs[i], j, colp, sh.lda, i, rs_b);
     const double ratio = b / (-a);
@@ -1048,9 +1062,12 @@ __global__ __launch_bounds__(256) void k_export_or_zero(
 // arithmetic, into `xlocal` without touching the tableau, so the exchange of the next
 // pivot column can travel while the update streams the shard.  pending == 0: no pivot
 // is waiting for its update (first iteration of a run), the column is copied as it is.
+// pending > 1: a chain of pivots has been set up (k_chain_finalize); the steps that really exist
+// (done flags) are applied in their order.
 __global__ __launch_bounds__(256) void k_export_lookahead(
     Tab T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand_local,
-    const double* __restrict__ colp, const double* __restrict__ rowp, int pending, double* __restrict__ xlocal) {
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const ChainStep* __restrict__ steps,
+    int pending, double* __restrict__ xlocal) {
   if (st->status != ST_RUNNING) return;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sh.lda) return;
@@ -1059,10 +1076,12 @@ __global__ __launch_bounds__(256) void k_export_lookahead(
   if (e >= 0 && i < sh.m) {
     const int64_t l = ordinal_of(e, sh.N) / sh.world;   // the local candidate is a column of this rank
     v = T.col(l)[i];
-    if (pending) {
-      const double rj = rowp[l];
-      if (rj != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(colp[i], rj)));   // k_update leaves columns with row' == 0 alone
-    }
+    int n = pending > 0 ? 1 : 0;
+    while (n > 0 && n < pending && steps[n].done) n++;
+    double rs[kMaxChain - 1];
+#pragma unroll
+    for (int s = 0; s < kMaxChain - 1; s++) rs[s] = s < n ? rowp[s * rstride + l] : 0.0;
+    v = chain_apply(v, n, colp, sh.lda, i, rs);          // the update leaves columns with row' == 0 alone
   }
   xlocal[i] = v;
 }

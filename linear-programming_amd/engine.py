@@ -81,6 +81,8 @@ def library():
         "lpamd_lookahead_setup": (ctypes.c_int, [vp, vp]),
         "lpamd_lookahead_export": (ctypes.c_int, [vp, vp, vp]),
         "lpamd_lookahead_update": (ctypes.c_int, [vp]),
+        "lpamd_chain_depth": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_chain_step": (ctypes.c_int, [vp, vp]),
         "lpamd_lookahead_select": (ctypes.c_int, [vp, vp, i32, vp, vp, vp]),
         "lpamd_fill_column": (ctypes.c_int, [vp, i64, ctypes.c_double]),
         "lpamd_set_basic_flag": (ctypes.c_int, [vp, i64, i32]),
@@ -298,6 +300,14 @@ class TableauEngine:
 
     def lookahead_update(self):
         _ck(self.L.lpamd_lookahead_update(self.h))
+
+    def chain_depth(self):
+        d = ctypes.c_int32()
+        _ck(self.L.lpamd_chain_depth(self.h, ctypes.byref(d)))
+        return d.value
+
+    def chain_step(self, xbuf_ptr):
+        _ck(self.L.lpamd_chain_step(self.h, ctypes.c_void_p(xbuf_ptr)))
 
     def lookahead_select(self, cands_ptr, xlocal_ptr, xbuf_ptr, stream=None):
         _ck(self.L.lpamd_lookahead_select(self.h, ctypes.c_void_p(cands_ptr), self.world, ctypes.c_void_p(xlocal_ptr),

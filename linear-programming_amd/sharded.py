@@ -21,6 +21,8 @@ bit-identical across ranks, so no further traffic is needed.
 GPUs, "gloo" in the CPU tests, which plug in a host stand-in for the shard.
 """
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -107,6 +109,12 @@ class EngineShard:
     def lookahead_update(self):
         self.eng.lookahead_update()
 
+    def chain_depth(self):
+        return self.eng.chain_depth()
+
+    def chain_step(self, xbuf):
+        self.eng.chain_step(xbuf.data_ptr())
+
     def lookahead_select(self, cands, xlocal, xbuf):
         """Enqueued on torch's current stream (the exchange stream), not on the engine's."""
         self.eng.lookahead_select(cands.data_ptr(), xlocal.data_ptr(), xbuf.data_ptr(),
@@ -186,9 +194,15 @@ class ShardedSolver:
     the owner and broadcasts the column from it.
     """
 
-    def __init__(self, shard, group=None, exchange="lookahead", poll_every=64, comm=None):
+    def __init__(self, shard, group=None, exchange="lookahead", poll_every=64, comm=None, chain=None):
         assert exchange in ("lookahead", "allreduce", "broadcast")
         self.shard = shard
+        # look-ahead loop: pivots set up per pass over the shard (1: one pivot per pass); shards without
+        # lpamd_chain_step (the host stand-in of the CPU tests) keep one pivot per pass
+        depth = shard.chain_depth() if hasattr(shard, "chain_depth") else 1
+        if chain is None:
+            chain = int(os.environ.get("LPAMD_SHARD_CHAIN", depth))
+        self.chain = max(1, min(int(chain), depth))
         if comm is None and dist.is_available() and dist.is_initialized():
             comm = DistComm(group)               # collectives also run for a world of one
         self.comm = comm
@@ -288,13 +302,23 @@ class ShardedSolver:
         enqueued = 0
         while True:
             n = self.poll_every if k < 0 else min(self.poll_every, k - enqueued)
-            for _ in range(n):
+            passes = (n + self.chain - 1) // self.chain
+            for _ in range(passes):
                 if two_streams:
                     sh.stream.wait_event(self.ev_arrived)
-                sh.lookahead_setup(self.xbuf)                 # ratio test + set-up of this pivot
-                sh.lookahead_export(self.cand, self.xlocal)   # next candidate, as the pending update will leave it
+                sh.lookahead_setup(self.xbuf)                 # ratio test + set-up of the first pivot of the pass
+                for _j in range(1, self.chain):
+                    # the next pivot of the chain: its exchange is on the critical path (nothing to hide it behind),
+                    # the pass over the shard that it saves is not
+                    sh.lookahead_export(self.cand, self.xlocal)
+                    self._lookahead_exchange()
+                    if two_streams:
+                        sh.stream.wait_event(self.ev_arrived)
+                    sh.chain_step(self.xbuf)
+                sh.lookahead_export(self.cand, self.xlocal)   # next candidate, as the pending pass will leave it
                 self._lookahead_exchange()                    # ... travels while ...
-                sh.lookahead_update()                         # ... the rank-1 update streams the shard
+                sh.lookahead_update()                         # ... the pass streams the shard
+            n = passes * self.chain
             enqueued += n
             res = sh.poll()
             if res != _eng.LIMIT or (k >= 0 and enqueued >= k):

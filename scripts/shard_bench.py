@@ -19,6 +19,7 @@ ap.add_argument("--n", type=int, default=65536)
 ap.add_argument("--steps", type=int, default=128)
 ap.add_argument("--strategy", default="max_cost")
 ap.add_argument("--exchange", default="lookahead", choices=["lookahead", "allreduce"])
+ap.add_argument("--chain", type=int, default=8, help="pivots set up per pass over the shard (look-ahead loop)")
 args = ap.parse_args()
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -53,9 +54,14 @@ def run_lookahead(k):
         shard.set_pivot_budget(k)
         shard.lookahead_export(cand, xlocal)
         exchange_ahead()
-        for _ in range(k):
+        for _ in range((k + args.chain - 1) // args.chain):
             shard.stream.wait_event(ev_arrived)
             shard.lookahead_setup(xbuf)
+            for _j in range(1, args.chain):
+                shard.lookahead_export(cand, xlocal)
+                exchange_ahead()
+                shard.stream.wait_event(ev_arrived)
+                shard.chain_step(xbuf)
             shard.lookahead_export(cand, xlocal)
             exchange_ahead()
             shard.lookahead_update()
@@ -86,6 +92,7 @@ el = time.perf_counter() - t0
 shard.eng.set_profiling(True)
 run(args.steps)
 ms, launches, active = shard.eng.update_stats()
+print("chain=%d " % args.chain, end="")
 print("world=%d shard: %d local columns, %.2f GB; %.3f ms per pivot (%.1f pivots/s); k_update %.3f ms avg (%.0f GB/s, %d active cols) -> non-update overhead %.3f ms" % (
     G, shard.eng.exchange_doubles() and (n + m + 1 + G - 1) // G, m * ((n + m + 1) // G + 1) * 8 / 1e9, el / args.steps * 1e3, args.steps / el,
     ms / launches, 16.0 * m * active / (ms / launches * 1e-3) / 1e9, active, el / args.steps * 1e3 - ms / launches))

@@ -326,18 +326,22 @@ def test_rccl_single_rank_solve_with_feasibility_phase(lpamd, exchange):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("chain", [1, 3, 8])
 @pytest.mark.parametrize("world", [1, 2, 3])
-def test_lookahead_exchange_overlaps_update_bit_exact(lpamd, world):
+def test_lookahead_exchange_overlaps_update_bit_exact(lpamd, monkeypatch, world, chain):
     """Look-ahead loop on shards large enough that the exchange stream really runs beside the
-    rank-1 update (one solver thread per rank on this GPU): trace, tableau and RHS replicas
-    must equal the single-engine device loop bit for bit, across two budgeted legs."""
+    rank-1 update (one solver thread per rank on this GPU), with 1, 3 and 8 pivots set up per pass
+    over the shard (lpamd_chain_step): trace, tableau and RHS replicas must equal the single-engine
+    one-pivot-per-pass device loop bit for bit, across two budgeted legs that end inside a chain."""
     import threading
     sharded = importlib.import_module("linear-programming_amd.sharded")
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
     m, n, seed, legs = 1536, 3072, 7, (23, 40)
+    monkeypatch.setenv("LPAMD_CHAIN", "1")
     ref = lpamd.TableauEngine(m, n + m)
+    monkeypatch.setenv("LPAMD_CHAIN", "8")
     ref.fill_synthetic(n, seed)
     assert ref.run_pivots(eng.MAX_COST, sum(legs)) == (eng.LIMIT, sum(legs))
     Tref, oref, bref = ref.download()
@@ -349,8 +353,9 @@ def test_lookahead_exchange_overlaps_update_bit_exact(lpamd, world):
             torch.cuda.set_device(0)
             shard = sharded.EngineShard(m, n + m, rank, world, dev)
             shard.eng.fill_synthetic(n, seed)
-            solver = sharded.ShardedSolver(shard, exchange="lookahead", poll_every=16,
+            solver = sharded.ShardedSolver(shard, exchange="lookahead", poll_every=16, chain=chain,
                                            comm=ThreadComm(shared, rank, world) if world > 1 else None)
+            assert solver.chain == chain
             for k in legs:
                 assert solver.run_pivots(eng.MAX_COST, k) == (eng.LIMIT, k)
             torch.cuda.synchronize()
