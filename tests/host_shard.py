@@ -45,7 +45,7 @@ class HostShard:
         self.winner = None
         self.trace = []
         self.budget_end = None
-        self.pending = None                     # look-ahead loop: (col', row', RHS factor) of a pivot whose update is due
+        self.pending = None                     # look-ahead loop: [(col', row', RHS factor)] of the pivots whose pass is due
         self.la_winner = None
 
     # ---- interface of EngineShard ----
@@ -156,13 +156,14 @@ class HostShard:
         a = col[r]
         f = -1.0 / a
         g = ce * f
-        rowp = self.T[r, :] * f
-        rhs_rowp = self.rhs[r] * f
-        self.obj = flush(self.obj + self.T[r, :] * g)
-        self.obj_const = float(flush(self.obj_const + self.rhs[r] * g))
+        row, rhs_r = self._pending_row(r), self._pending_rhs()[r]
+        rowp = row * f
+        rhs_rowp = rhs_r * f
+        self.obj = flush(self.obj + row * g)
+        self.obj_const = float(flush(self.obj_const + rhs_r * g))
         colp = col.copy()
         colp[r] = 1.0 + a
-        self.pending = (colp, rowp, rhs_rowp)
+        self.pending = (self.pending or []) + [(colp, rowp, rhs_rowp)]
         for l, gc in enumerate(self.gcols):
             if gc == e:
                 self.obj[l] = 0.0
@@ -173,10 +174,30 @@ class HostShard:
         self.trace.append((int(e), int(r)))
 
     def _pivot_update(self):
-        colp, rowp, rhs_rowp = self.pending
-        self.pending = None
-        self.T = np.asfortranarray(flush(self.T + colp[:, None] * rowp[None, :]))
-        self.rhs = flush(self.rhs + colp * rhs_rowp)
+        steps, self.pending = self.pending, None
+        for colp, rowp, rhs_rowp in steps:          # one pass, the pivots in their order
+            self.T = np.asfortranarray(flush(self.T + colp[:, None] * rowp[None, :]))
+            self.rhs = flush(self.rhs + colp * rhs_rowp)
+
+    # what the pivots that wait for their pass will make of one row, of the RHS, of one local column
+    def _pending_row(self, r):
+        row = np.array(self.T[r, :], dtype=np.float64)
+        for colp, rowp, _ in self.pending or []:
+            row = np.where(rowp != 0.0, flush(row + colp[r] * rowp), row)
+        return row
+
+    def _pending_rhs(self):
+        rhs = self.rhs
+        for colp, _, rhs_rowp in self.pending or []:
+            rhs = flush(rhs + colp * rhs_rowp)
+        return rhs
+
+    def _pending_col(self, l):
+        col = np.array(self.T[:, l], dtype=np.float64)
+        for colp, rowp, _ in self.pending or []:
+            if rowp[l] != 0.0:
+                col = flush(col + colp * rowp[l])
+        return col
 
     # ---- look-ahead exchange (MAX_COST), same four steps as EngineShard ----
     def lookahead_export(self, cand, xlocal):
@@ -188,13 +209,7 @@ class HostShard:
         e = int(cand.numpy().view(np.int64)[1])
         if e < 0:
             return
-        l = self._local(e)
-        col = np.array(self.T[:, l], dtype=np.float64)
-        if self.pending is not None:
-            colp, rowp, _ = self.pending
-            if rowp[l] != 0.0:
-                col = flush(col + colp * rowp[l])
-        x[: self.m] = col
+        x[: self.m] = self._pending_col(self._local(e))
 
     def lookahead_select(self, cands, xlocal, xbuf):
         e, r, owner, res, win = eng.fold_candidates(eng.MAX_COST, cands.numpy(), self.world, self.N)
@@ -224,6 +239,26 @@ class HostShard:
     def lookahead_update(self):
         if self.pending is not None:
             self._pivot_update()
+
+    def chain_depth(self):
+        return 8
+
+    def chain_step(self, xbuf):
+        """One more pivot set up before the pass (lpamd_chain_step): no-op when the chain cannot go on."""
+        if self.pending is None or self.status != eng.LIMIT:
+            return
+        if self.budget_end is not None and len(self.trace) >= self.budget_end:
+            return
+        if self.la_winner is None:
+            return
+        e = int(self.la_winner.view(np.int64)[1])
+        col = np.array(xbuf.numpy()[: self.m], dtype=np.float64)
+        rows = np.nonzero(f32(col) <= np.float32(-1e-6))[0]
+        if not len(rows):
+            return
+        ratios = self._pending_rhs()[rows] / (-col[rows])
+        r = int(rows[int(np.argmin(ratios))])
+        self._pivot_setup(int(self.basis[r]), e, r, float(self.la_winner[3]), col)
 
     # ---- pieces of the feasibility phase ----
     def owns(self, col):

@@ -61,6 +61,13 @@ def test_two_rank_loop_matches_oracle(tmp_path, case, strategy, exchange):
     _check_loop(tmp_path, case, strategy, exchange, 2)
 
 
+@pytest.mark.parametrize("chain", ["1", "3"])
+def test_two_rank_lookahead_loop_other_chain_depths(tmp_path, monkeypatch, chain):
+    """The look-ahead loop sets up 8 pivots per pass by default (the cases above); here one and three."""
+    monkeypatch.setenv("LPAMD_SHARD_CHAIN", chain)
+    _check_loop(tmp_path, ("synthetic", 37, 70, 5), "max_cost", "lookahead", 2)
+
+
 def test_four_rank_lookahead_loop_matches_oracle(tmp_path):
     _check_loop(tmp_path, ("synthetic", 37, 70, 5), "max_cost", "lookahead", 4)
 
