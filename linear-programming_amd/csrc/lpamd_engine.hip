@@ -332,6 +332,7 @@ void launch_update(lpamd_engine* e, int grid, bool nt, bool fuse_pr) {
 }
 
 int enqueue_update(lpamd_engine* e, bool fuse_pr) {
+  e->loop_depth = 1;   // a pass with one pivot: the step records of an earlier chain do not describe it
   if (fuse_pr && e->update_slot >= 0) return set_err(LPAMD_E_STATE, "the two-launch loop has no fused max-reduction pricing");
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
@@ -1368,8 +1369,10 @@ int lpamd_lookahead_update(lpamd_engine* e) {
   e->update_pending = false;
   const int steps = e->pending_steps;
   e->pending_steps = 0;
-  e->loop_depth = steps;
-  if (steps > 1) return enqueue_chain_update(e);
+  if (steps > 1) {
+    e->loop_depth = steps;
+    return enqueue_chain_update(e);
+  }
   return enqueue_update(e, false);
 }
 
