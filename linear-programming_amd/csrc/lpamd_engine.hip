@@ -1314,10 +1314,10 @@ int lpamd_apply_pivot(lpamd_engine* e, int32_t strategy, int64_t col, int64_t r,
 int lpamd_lookahead_export(lpamd_engine* e, void* cand_dev, void* xlocal_dev) {
   CHECK_LOADED(e);
   if (!cand_dev || !xlocal_dev) return set_err(LPAMD_E_ARG, "lookahead_export: null buffer");
-  LP_TRY(enqueue_pricing(e, LPAMD_MAX_COST, (Candidate*)cand_dev));
-  hipLaunchKernelGGL(k_export_lookahead, dim3((unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->sh, e->st,
-                     (const Candidate*)cand_dev, e->colp, e->rowp, e->rstride, e->steps, e->update_pending ? e->pending_steps : 0,
-                     (double*)xlocal_dev);
+  if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
+  hipLaunchKernelGGL(k_export_lookahead, dim3((unsigned)((e->sh.lda + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0,
+                     e->stream, e->T, e->sh, e->st, e->part_v, e->part_i, e->n_price_part, (Candidate*)cand_dev, e->colp, e->rowp,
+                     e->rstride, e->steps, e->update_pending ? e->pending_steps : 0, (double*)xlocal_dev);
   return check_launch("k_export_lookahead");
 }
 

@@ -1064,17 +1064,29 @@ __global__ __launch_bounds__(256) void k_export_or_zero(
 // is waiting for its update (first iteration of a run), the column is copied as it is.
 // pending > 1: a chain of pivots has been set up (k_chain_finalize); the steps that really exist
 // (done flags) are applied in their order.
-__global__ __launch_bounds__(256) void k_export_lookahead(
-    Tab T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand_local,
-    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const ChainStep* __restrict__ steps,
-    int pending, double* __restrict__ xlocal) {
+// The local candidate is folded here from the pricing partials the last set-up left (every
+// workgroup folds them itself, workgroup 0 writes the 32-byte record), which saves the launch of
+// k_price_fold in front of every exchange.
+__global__ __launch_bounds__(kPartialThreads) void k_export_lookahead(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
+    Candidate* __restrict__ cand_local, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
+    const ChainStep* __restrict__ steps, int pending, double* __restrict__ xlocal) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
+  double ce;
+  int64_t l;
+  fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    Candidate c;
+    c.key = ce; c.ce = ce; c.row = -1;
+    c.gcol = l < 0 ? -1 : gcol_of(l * sh.world + sh.rank, sh.N);
+    *cand_local = c;
+  }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= sh.lda) return;
-  const int64_t e = cand_local->gcol;
   double v = 0.0;
-  if (e >= 0 && i < sh.m) {
-    const int64_t l = ordinal_of(e, sh.N) / sh.world;   // the local candidate is a column of this rank
+  if (l >= 0 && i < sh.m) {
     v = T.col(l)[i];
     int n = pending > 0 ? 1 : 0;
     while (n > 0 && n < pending && steps[n].done) n++;
