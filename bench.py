@@ -166,8 +166,10 @@ def main():
     sync_all()
     el = time.perf_counter() - t0
     upd_ms, launches, active = eng.update_stats()
-    pass_pivots, pass_streamed, _ = eng.pass_stats()
+    last_pivots, pass_streamed, _ = eng.pass_stats()
     eng.set_profiling(False)
+    # pivots per launch over the timed region (the last pass may be shorter when K is no multiple of the chain depth)
+    pass_pivots = max(1, round(K / launches)) if launches and last_pivots > 0 else 1
     assert done == K and res == lp.LIMIT, "timed region ended early: result %d after %d pivots" % (res, done)
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)

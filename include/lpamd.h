@@ -120,7 +120,9 @@ int lpamd_objective_constant(lpamd_engine* eng, double* out);
 int lpamd_pivot_count(const lpamd_engine* eng, int64_t* n);
 int lpamd_trace(const lpamd_engine* eng, int64_t* e, int64_t* r, int64_t cap, int64_t* n);
 
-/* HIP-event timing of the rank-1 update kernel (off by default). */
+/* HIP-event timing of the rank-1 update kernel (off by default).  active_columns: columns the
+ * pivots of one launch touch, summed over its pivots and averaged over the launches since
+ * profiling was switched on (a launch may apply a chain of pivots, see lpamd_pass_stats). */
 int lpamd_set_profiling(lpamd_engine* eng, int32_t on);
 int lpamd_update_stats(lpamd_engine* eng, double* total_ms, int64_t* launches, int64_t* active_columns);
 /* The device loop of lpamd_run_pivots / lpamd_solve applies a chain of up to 8 MAX_COST

@@ -1160,6 +1160,8 @@ int lpamd_set_profiling(lpamd_engine* e, int32_t on) {
   e->prof_ms = 0.0;
   e->prof_launches = 0;
   e->prof_active = 0;
+  HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep), e->stream));   // running totals of the chained passes
+  HIP_TRY(hipStreamSynchronize(e->stream));
   return LPAMD_OK;
 }
 
@@ -1179,6 +1181,8 @@ int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int
     ChainStep cs[kMaxChain];
     LP_TRY(read_local(e, e->steps, cs, sizeof(cs)));
     for (int s = 1; s < e->loop_depth && cs[s].done; s++) e->prof_active += cs[s].n_touched;
+    // passes of different lengths (a budget that ends inside a chain): the average per pass since profiling began
+    if (cs[0].r > 0) e->prof_active = cs[0].e / cs[0].r;
   }
   if (total_ms) *total_ms = e->prof_ms;
   if (launches) *launches = e->prof_launches;

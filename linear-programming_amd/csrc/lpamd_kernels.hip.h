@@ -673,6 +673,18 @@ struct ChainStep {   // pivots 1.. of the pass (pivot 0 is described by PivotSta
   double a, ce, f, g;
 };
 
+// Record 0 is free (pivot 0 of a pass lives in PivotState) and keeps running totals over the passes
+// since profiling was switched on: e = columns touched summed over the pivots, r = passes,
+// d = columns streamed, a = pivots.  Written by the bookkeeping thread of the update kernel only.
+__device__ __forceinline__ void chain_account(ChainStep* steps, int n_steps, int n_active0, int n_list) {
+  int64_t touched = n_active0;
+  for (int s = 1; s < n_steps; s++) touched += steps[s].n_touched;
+  steps[0].e += touched;
+  steps[0].r += 1;
+  steps[0].d += n_list;
+  steps[0].a += (double)n_steps;
+}
+
 __device__ __forceinline__ double chain_apply(double v, int j, const double* __restrict__ colp, int64_t lda, int64_t i,
                                               const double* rs) {
 #pragma unroll
@@ -855,7 +867,7 @@ template <int kUnroll, bool kNT>
 __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
     Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
     const int32_t* __restrict__ active, const int32_t* __restrict__ lists, int depth,
-    PivotState* __restrict__ st, const ChainStep* __restrict__ steps, Shape sh,
+    PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
     uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
   if (st->status != ST_RUNNING) return;
   int n_steps = 1;
@@ -875,6 +887,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
     };
     flip(st->e, st->d, st->r);
     for (int s = 1; s < n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
+    chain_account(steps, n_steps, st->n_active, n_list);
     if (n_steps > 1) {   // no other workgroup of this launch reads these fields
       const ChainStep& z = steps[n_steps - 1];
       st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
@@ -925,7 +938,7 @@ template <int kK, int kR, int kC, bool kNT>
 __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
     Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
     const int32_t* __restrict__ active, const int32_t* __restrict__ lists, int depth,
-    PivotState* __restrict__ st, const ChainStep* __restrict__ steps, Shape sh,
+    PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
     uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis, int n_slabs) {
   if (st->status != ST_RUNNING) return;
   int n_steps = 1;
@@ -944,6 +957,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
     };
     flip(st->e, st->d, st->r);
     for (int s = 1; s < n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
+    chain_account(steps, n_steps, st->n_active, n_list);
     if (n_steps > 1) {
       const ChainStep& z = steps[n_steps - 1];
       st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;

@@ -152,3 +152,20 @@ def test_slab_pass_with_col_in_registers(lpamd, monkeypatch, depth, slab, chain,
     assert eng.trace() == dt.trace()
     assert_same_tableau(eng, dt)
     eng.close()
+
+
+def test_update_stats_average_over_passes_of_different_length(lpamd, monkeypatch, depth):
+    """13 pivots with chains of 8 are a pass of 8 and a pass of 5: active_columns is the mean per launch."""
+    if depth != 8:
+        pytest.skip("one run is enough")
+    m, n = 600, 1100
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, 7)
+    eng.set_profiling(True)
+    assert eng.run_pivots(lpamd.MAX_COST, 13) == (lpamd.LIMIT, 13)
+    ms, launches, active = eng.update_stats()
+    assert launches == 2 and ms > 0
+    assert 6.5 * n <= active <= 6.5 * (n + 14)
+    assert eng.pass_stats()[0] == 5
+    eng.set_profiling(False)
+    eng.close()
