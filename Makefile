@@ -13,7 +13,7 @@ CXXFLAGS := -O2 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(CSRC)/host -Wal
 all: engine host oracle
 
 engine: $(LIBDIR)/liblpamd.so
-$(LIBDIR)/liblpamd.so: $(CSRC)/lpamd_engine.hip $(CSRC)/lpamd_kernels.hip.h $(CSRC)/lpamd_revised.hip.h $(CSRC)/lpamd_revised_kernels.hip.h include/lpamd.h
+$(LIBDIR)/liblpamd.so: $(CSRC)/lpamd_engine.hip $(wildcard $(CSRC)/*.hip.h) include/lpamd.h
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/lpamd_engine.hip
 

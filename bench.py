@@ -7,16 +7,22 @@ resident in HBM before the timed region starts.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--strategy max_cost|max_reduction]
 
-N == 1 runs the device-resident loop of the C ABI (lpamd_run_pivots); N > 1 is
-launched by torch.distributed.run with one rank per GPU and runs the
-column-sharded loop (RCCL all-gather of candidates + integer sum-all-reduce of
-the pivot column, both on a second stream beside the rank-1 update for
-max_cost).  Rank 0 prints ONE JSON line.
+N == 1 runs the device-resident loop of the C ABI (lpamd_run_pivots).  N > 1 runs the
+column-sharded loop of the library (lpamd_group_*: one RCCL all-gather per pivot, chains of
+pivots per pass over the shard), one process per GPU: either the driver starts the ranks with
+torch.distributed.run, or a plain `python bench.py --gpus N` starts them itself (as a child
+torch.distributed.run, before this process touches a GPU).  Rank 0 prints ONE JSON line.
+
+The MAX_COST loop applies a chain of pivots per pass over the tableau, so the warm-up and the
+timed region are rounded UP to whole passes; the line reports the pivots actually timed
+("steps") next to the request ("steps_requested").
 """
 import argparse
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,22 +48,23 @@ DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
 
-def pmc_traffic(config, world, pivots_per_launch=1):
-    """HBM bytes per k_update launch from the committed rocprofv3 PMC passes of this
-    same command (profiles/*/pmc_hbm_traffic_*.json: FETCH_SIZE doubled as gfx950
-    requires, plus WRITE_SIZE).  None when no pass exists for the configuration."""
+def pmc_traffic_ratio(config, world, chained):
+    """HBM bytes the update kernel really moved per byte it is meant to stream, from the committed
+    rocprofv3 PMC passes of this same command (profiles/*/pmc_hbm_traffic_*.json: FETCH_SIZE doubled
+    as gfx950 requires, plus WRITE_SIZE; one pass per counter).  The newest file for the
+    configuration and the kind of pass (chain of pivots or one pivot) wins; None if there is none."""
     import glob
     if world != 1:
-        return None
-    best = None
+        return None, None
+    best, src = None, None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic_*.json"))):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("config") == config and d.get("pivots_per_launch", 1) == pivots_per_launch:
-            best = d.get("traffic_bytes_per_launch")
-    return best
+        if d.get("config") == config and (d.get("pivots_per_launch", 1) > 1) == chained and d.get("traffic_over_streamed"):
+            best, src = float(d["traffic_over_streamed"]), os.path.relpath(f, ROOT)
+    return best, src
 
 
 def cpu_baseline(m, n, seed, strategy_name, budget_s=20.0):
@@ -95,6 +102,24 @@ def cpu_baseline(m, n, seed, strategy_name, budget_s=20.0):
     }
 
 
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n_gpus, argv, port):
+    """The command that starts one rank per GPU for a plain `python bench.py --gpus N`."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def round_up(x, q):
+    return (x + q - 1) // q * q
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,28 +129,28 @@ def main():
     ap.add_argument("--strategy", default="max_cost", choices=["max_cost", "max_reduction"])
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange", default=os.environ.get("LPAMD_EXCHANGE", "lookahead"), choices=["lookahead", "allreduce", "broadcast"],
-                    help="N > 1: how the shards exchange the entering column (see linear-programming_amd/sharded.py)")
+    ap.add_argument("--exact-steps", action="store_true", help="time exactly --steps pivots even when that ends inside a pass")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+        # Not started by a launcher: start one rank per GPU as a child, before anything here touches a GPU.
+        sys.exit(subprocess.call(launch_command(args.gpus, sys.argv[1:], free_port())))
 
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # LPAMD_BENCH_FORCE_SHARDED=1 runs the multi-rank code path (RCCL collectives included)
-    # even for a world of one, to rehearse it on a one-GPU box.
+    # LPAMD_BENCH_FORCE_SHARDED=1 runs the sharded loop (RCCL all-gather included) for a world of one,
+    # to rehearse it on a one-GPU box; LPAMD_BENCH_SHARD="r/w" times shard r of a world of w alone.
     force_sharded = os.environ.get("LPAMD_BENCH_FORCE_SHARDED", "0") == "1"
-    use_dist = world > 1 or (force_sharded and "MASTER_PORT" in os.environ)
+    use_dist = world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -134,7 +159,6 @@ def main():
     m, n = CONFIGS[args.config]
     N = n + m
     strat = lp.STRATEGY[args.strategy]
-    K, W = args.steps, args.warmup
 
     def sync_all():
         torch.cuda.synchronize()
@@ -142,51 +166,60 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    group = None
     if world == 1 and not force_sharded:
         eng = lp.TableauEngine(m, N)
         eng.fill_synthetic(n, args.seed)
         run = lambda k: eng.run_pivots(strat, k)
+        depth = eng.loop_depth(strat)
+        exchange = "none (device-resident loop)"
     else:
-        from importlib import import_module
-        sharded = import_module("linear-programming_amd.sharded")
-        shard = sharded.EngineShard(m, N, rank, world, dev)
-        shard.eng.fill_synthetic(n, args.seed)
-        eng = shard.eng
-        solver = sharded.ShardedSolver(shard, exchange=args.exchange)
-        run = lambda k: solver.run_pivots(strat, k)
+        if use_dist:
+            ids = [lp.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            group = lp.ShardGroup.join(m, N, rank, world, ids[0])
+        else:
+            group = lp.ShardGroup(m, N, 1, devices=[local_rank])
+        group.fill_synthetic(n, args.seed)
+        eng = group.engine(0)
+        run = lambda k: group.run_pivots(strat, k)
+        depth = group.chain() if strat == lp.MAX_COST else 1
+        exchange = "one RCCL all-gather per pivot (record + candidate column per rank), inside the library"
 
+    K, W = args.steps, args.warmup
+    if not args.exact_steps:
+        K, W = round_up(max(K, 1), depth), round_up(W, depth)
     res, done = run(W)
     assert done == W and res == lp.LIMIT, "warm-up ended early: result %d after %d pivots" % (res, done)
     sync_all()
-    # HIP events around every rank-1 update launch of the timed region, recorded on the engine's own
-    # stream (two event records per pivot; read back after the region)
+    # HIP events around every rank-1 update launch of the timed region, recorded on the engine's own stream
     eng.set_profiling(True)
     t0 = time.perf_counter()
     res, done = run(K)
     sync_all()
     el = time.perf_counter() - t0
-    upd_ms, launches, active = eng.update_stats()
-    last_pivots, pass_streamed, _ = eng.pass_stats()
+    upd_ms, passes, pivots, streamed_cols, touched_cols = eng.profile_totals()
     eng.set_profiling(False)
-    # pivots per launch over the timed region (the last pass may be shorter when K is no multiple of the chain depth)
-    pass_pivots = max(1, round(K / launches)) if launches and last_pivots > 0 else 1
     assert done == K and res == lp.LIMIT, "timed region ended early: result %d after %d pivots" % (res, done)
+    assert pivots == K or passes == 0, "device totals (%d pivots) disagree with the %d pivots timed" % (pivots, K)
     if use_dist:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    avg_ms = upd_ms / max(launches, 1)
-    # algorithmic bytes: every entry of an active local column is read once and written once PER PIVOT
-    # (16*m*n_active); a pass that applies a chain of pivots counts the columns of each of them
-    # (`active`), while it streams the tableau only once (`pass_streamed` columns)
-    algo_bytes = 16.0 * m * active
-    streamed_bytes = 16.0 * m * pass_streamed
-    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+    # HBM traffic of the pass kernel: every streamed column is read once and written once per PASS (16*m bytes);
+    # the algorithmic figure counts 16*m bytes per column a PIVOT touches, i.e. once per pivot of the chain.
+    streamed_bytes = 16.0 * m * streamed_cols
+    algo_bytes = 16.0 * m * touched_cols
+    secs = max(upd_ms, 1e-9) * 1e-3
+    achieved = streamed_bytes / secs / 1e9 if passes else 0.0
     if use_dist:
         t = torch.tensor([achieved], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)   # report the slowest rank's kernel rate
         achieved = float(t.item())
+    chained = passes > 0 and pivots > passes
+    ratio, ratio_src = pmc_traffic_ratio(args.config, world, chained)
+    per_launch = streamed_bytes / max(passes, 1)
 
     out = {
         "metric": "simplex_pivots_per_sec",
@@ -195,6 +228,8 @@ def main():
         "n_gpus": world,
         "steps": K,
         "warmup": W,
+        "steps_requested": args.steps,
+        "warmup_requested": args.warmup,
         "ms_per_step": round(el / K * 1e3, 5),
         "higher_is_better": True,
         "scaling": "strong",
@@ -203,19 +238,22 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.config, "m": m, "n": n, "stored_columns": N + 1, "strategy": args.strategy,
                    "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world,
-                   "exchange": (args.exchange if (world > 1 or force_sharded) else "none (device-resident loop)")},
+                   "exchange": exchange, "pivots_per_pass": depth},
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),
+        "pivots_per_pass": round(pivots / max(passes, 1), 3),
+        "algorithmic_GBps": round(algo_bytes / secs / 1e9, 1) if passes else 0.0,
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args.config, world, pass_pivots),
-                     "kernel": "k_update_slab" if pass_pivots > 1 else "k_update", "avg_launch_ms": round(avg_ms, 5),
-                     "launches": int(launches), "algorithmic_bytes_per_launch": algo_bytes, "active_columns": int(active),
-                     "pivots_per_launch": int(pass_pivots), "streamed_columns": int(pass_streamed),
-                     "streamed_bytes_per_launch": streamed_bytes,
-                     "streamed_GBps": round(streamed_bytes / (avg_ms * 1e-3) / 1e9, 1) if launches else 0.0,
-                     "note": "achieved = algorithmic bytes (16*m*n_active per pivot x pivots per launch) / launch time; a launch "
-                             "applies a chain of pivots in ONE pass over the tableau, so the HBM traffic of a launch is "
-                             "streamed_bytes_per_launch (PMC: traffic) and achieved may exceed the HBM peak"},
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": round(ratio * per_launch) if ratio else None,
+                     "traffic_source": ratio_src,
+                     "kernel": "k_update_slab" if chained else "k_update", "avg_launch_ms": round(upd_ms / max(passes, 1), 5),
+                     "launches": int(passes), "streamed_bytes_per_launch": per_launch,
+                     "algorithmic_bytes_per_launch": algo_bytes / max(passes, 1),
+                     "note": "achieved = HBM bytes one launch streams (16*m per column it reads and writes, once per pass) / its "
+                             "duration (HIP events on the engine's stream); a launch applies pivots_per_pass pivots to every entry, "
+                             "so the per-pivot algorithmic bytes (16*m*n_active per pivot) give algorithmic_GBps, which may exceed the "
+                             "peak; traffic = PMC bytes per launch (committed profile, scaled to this run's streamed columns)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -224,6 +262,8 @@ def main():
             out["cpu_baseline"] = {"value": None, "unit": "pivots/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if group is not None:
+        group.close()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -25,9 +25,9 @@
  *    memory (HBM) until lpamd_destroy.
  *  - multi-GPU: one engine per process/GPU holds the columns whose ordinal
  *    (global id, with the RHS column skipped) is congruent to `rank` modulo
- *    `world`, plus a replica of the RHS column.  The caller moves the two small
- *    exchange buffers between ranks (all-gather of candidates, broadcast of the
- *    pivot column); the library itself calls no collective.
+ *    `world`, plus a replica of the RHS column.  Either the library runs the shards of an
+ *    LP itself, RCCL collectives included (lpamd_group_*), or the caller drives the engines
+ *    step by step and moves the exchange buffers between ranks with collectives of its own.
  */
 #ifndef LPAMD_H_
 #define LPAMD_H_
@@ -133,6 +133,14 @@ int lpamd_update_stats(lpamd_engine* eng, double* total_ms, int64_t* launches, i
  * the pivots it applied, the columns it streamed, and the sum of the columns the pivots
  * touch one by one (what lpamd_update_stats reports as active_columns). */
 int lpamd_pass_stats(lpamd_engine* eng, int32_t* pivots, int64_t* streamed_columns, int64_t* touched_columns);
+/* Totals over all passes since lpamd_set_profiling(eng, 1): milliseconds inside the update kernel (HIP events on
+ * the engine's stream), passes (= launches of that kernel), pivots they applied, columns they streamed (a column
+ * is read and written once per pass: 16*m bytes of HBM traffic each) and columns the pivots touch one by one
+ * (the algorithmic 16*m bytes per column and pivot).  Any pointer may be NULL. */
+int lpamd_profile_totals(lpamd_engine* eng, double* total_ms, int64_t* passes, int64_t* pivots, int64_t* streamed_columns,
+                         int64_t* touched_columns);
+/* Pivots one pass of the device loop (lpamd_run_pivots / lpamd_solve) applies at most for `strategy`. */
+int lpamd_loop_depth(const lpamd_engine* eng, int32_t strategy, int32_t* depth);
 
 /* ---- multi-GPU steps (column shards; the caller runs the collectives) ----
  * These split one iteration of reference lp_simplex_tableau.cc:181-377 at the
@@ -223,6 +231,55 @@ int lpamd_set_basic_flag(lpamd_engine* eng, int64_t col, int32_t flag);
 int lpamd_pivot_shard(lpamd_engine* eng, int64_t d, int64_t e, int64_t r, double ce, const void* xbuf_dev);
 /* terminal status after step 4 (synchronises): LPAMD_LIMIT = still running */
 int lpamd_poll(lpamd_engine* eng, int32_t* result);
+
+/* ---- column shards over several GPUs, RCCL inside the library --------------
+ * One LP, its columns dealt round-robin over `world` shards (one lpamd_engine each, see the
+ * multi-GPU steps above), driven through TableauSimplexSolve (reference
+ * lp_simplex_tableau.cc:173-379) by the library itself.  The reference has no counterpart: its only
+ * parallelism is OpenMP inside List::Map (reference lp_simplex_tableau.cc:253-309).  Per pivot the
+ * shards trade ONE RCCL all-gather: every rank sends its best local candidate, record and column
+ * (world * (64 + 8 * lda) bytes arrive per rank), every rank folds the records with the reference's
+ * tie-break (largest key, lowest column) and takes the winner's column; MAX_COST sets up several
+ * pivots per pass over the shard (lpamd_group_chain), the exchange of the pass after travels on a
+ * second stream beside the rank-1 update.  Results equal the single-engine loop bit for bit.
+ *
+ * lpamd_group_create: ONE process drives n_shards GPUs (devices[k] for shard k, NULL = 0..n-1),
+ * one host thread and one communicator per shard (ncclCommInitAll).  With
+ * LPAMD_GROUP_LOCAL_EXCHANGE the shards trade through device copies instead of RCCL and may
+ * share a GPU (RCCL refuses that): for tests on a one-GPU machine.
+ * lpamd_group_create_rank: one process PER GPU; this process holds shard `rank` on the current
+ * device and joins the communicator named by the 128-byte id that rank 0 made with
+ * lpamd_comm_unique_id and the caller delivered (any channel).  Collective: every rank calls it.
+ * Every lpamd_group_* call below is collective in that mode. */
+typedef struct lpamd_group lpamd_group;
+#define LPAMD_COMM_ID_BYTES 128
+enum { LPAMD_GROUP_LOCAL_EXCHANGE = 1 };
+int lpamd_comm_unique_id(void* id_out);
+int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards, const int32_t* devices, int32_t flags);
+int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id);
+int lpamd_group_destroy(lpamd_group* g);
+/* shards held by this process / shards of the LP; the engine of a local shard (owned by the group:
+ * for traces, statistics and read-back through the lpamd_* calls, not for pivoting) */
+int lpamd_group_shards(const lpamd_group* g, int32_t* n_local, int32_t* world);
+int lpamd_group_engine(lpamd_group* g, int32_t local_index, lpamd_engine** out);
+/* pivots one pass over a shard sets up at most in the MAX_COST loop (LPAMD_SHARD_CHAIN overrides) */
+int lpamd_group_chain(lpamd_group* g, int32_t* pivots_per_pass);
+/* as lpamd_upload / lpamd_fill_synthetic / lpamd_download, every local shard taking or filling its own columns */
+int lpamd_group_upload(lpamd_group* g, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic);
+int lpamd_group_fill_synthetic(lpamd_group* g, int64_t n_struct, uint64_t seed);
+int lpamd_group_download(lpamd_group* g, double* T, int64_t ld, double* obj, uint8_t* is_basic);
+/* needTableauInitialization / TableauSimplexInitialize / TableauSimplexSolve / the loop body / TableauPivot
+ * (reference lp_simplex_tableau.cc:54-62, 64-171, 173-379, 181-377, 10-52) over the shards */
+int lpamd_group_need_init(lpamd_group* g, int32_t* out);
+int lpamd_group_phase1(lpamd_group* g, int32_t strategy, int32_t* result);
+int lpamd_group_solve(lpamd_group* g, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots);
+int lpamd_group_run_pivots(lpamd_group* g, int32_t strategy, int64_t k, int32_t* result, int64_t* done);
+int lpamd_group_pivot(lpamd_group* g, int64_t d, int64_t e, int64_t r);
+/* as lpamd_column_values (assembled over all ranks) / lpamd_objective_constant / lpamd_pivot_count / lpamd_trace */
+int lpamd_group_column_values(lpamd_group* g, double* x_Np2);
+int lpamd_group_objective_constant(lpamd_group* g, double* out);
+int lpamd_group_pivot_count(lpamd_group* g, int64_t* n);
+int lpamd_group_trace(lpamd_group* g, int64_t* e, int64_t* r, int64_t cap, int64_t* n);
 
 /* ---- revised simplex on the tableau (one GPU) ------------------------------
  * The reference's other tableau algorithm, `solver <file> revised_simplex_tableau`

@@ -6,5 +6,5 @@ built library, or creating an engine without a GPU, raises.
 """
 from .engine import (  # noqa: F401
     ERROR, UNBOUNDED, NOSOLUTION, SOLVED, LIMIT, MAX_COST, MAX_REDUCTION, STRATEGY,
-    LpamdError, RevisedTableauEngine, TableauEngine, library, library_path,
+    LpamdError, RevisedTableauEngine, ShardGroup, TableauEngine, comm_unique_id, library, library_path,
 )

@@ -5,6 +5,7 @@
 #include "lp_model.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "host_assert.h"
 #include "lpamd.h"
@@ -166,28 +167,51 @@ HostTableau LPModel::BuildHostTableau() {
 }
 
 void LPModel::ToTableau(TableauStorageFormat format) {
-  if (engine_ != nullptr || rev_engine_ != nullptr) return;
+  if (HasTableau() || rev_engine_ != nullptr) return;
   HostTableau h = BuildHostTableau();
   LP_ASSERT(h.m > 0 && h.N > 0);
   if (format == COLUMN_ONLY) {
     // The storage format upstream picks for the revised simplex (reference solver.cc:139,
     // lp_revised_simplex_tableau_test.cc:14); here it selects the engine that keeps the
     // tableau untouched and carries the basis inverse.
-    CheckEngine(lpamd_rev_create(&rev_engine_, h.m, h.N, nullptr), "ToTableau: creating the GPU engine failed");
-    CheckEngine(lpamd_rev_upload(rev_engine_, h.T.data(), h.m, h.obj.data(), h.is_basic.data(), opt_reverted_ ? 1 : 0),
+    lpamd_rev_engine* rev = nullptr;
+    CheckEngine(lpamd_rev_create(&rev, h.m, h.N, nullptr), "ToTableau: creating the GPU engine failed");
+    rev_engine_.reset(rev, [](lpamd_rev_engine* p) { lpamd_rev_destroy(p); });
+    CheckEngine(lpamd_rev_upload(rev, h.T.data(), h.m, h.obj.data(), h.is_basic.data(), opt_reverted_ ? 1 : 0),
                 "ToTableau: upload failed");
     return;
   }
-  CheckEngine(lpamd_create(&engine_, h.m, h.N, 0, 1, nullptr), "ToTableau: creating the GPU engine failed");
-  CheckEngine(lpamd_upload(engine_, h.T.data(), h.m, h.obj.data(), h.is_basic.data()), "ToTableau: upload failed");
+  int shards = n_gpus_;
+  if (shards <= 0) {
+    const char* env = std::getenv("LPAMD_GPUS");
+    shards = env ? std::atoi(env) : 1;
+  }
+  shards = (int)std::min<int64_t>(std::max(shards, 1), h.N + 1);   // never more shards than columns
+  if (shards > 1) {
+    // column shards, one per GPU (reference has no counterpart; results are those of one GPU bit for bit)
+    std::vector<int32_t> devices(shards, 0);
+    for (int k = 0; k < shards && !share_one_gpu_; k++) devices[k] = k;
+    lpamd_group* group = nullptr;
+    CheckEngine(lpamd_group_create(&group, h.m, h.N, shards, devices.data(), share_one_gpu_ ? LPAMD_GROUP_LOCAL_EXCHANGE : 0),
+                "ToTableau: creating the GPU shards failed");
+    group_.reset(group, [](lpamd_group* p) { lpamd_group_destroy(p); });
+    CheckEngine(lpamd_group_upload(group, h.T.data(), h.m, h.obj.data(), h.is_basic.data()), "ToTableau: upload failed");
+    return;
+  }
+  lpamd_engine* eng = nullptr;
+  CheckEngine(lpamd_create(&eng, h.m, h.N, 0, 1, nullptr), "ToTableau: creating the GPU engine failed");
+  engine_.reset(eng, [](lpamd_engine* p) { lpamd_destroy(p); });
+  CheckEngine(lpamd_upload(eng, h.T.data(), h.m, h.obj.data(), h.is_basic.data()), "ToTableau: upload failed");
 }
 
 // reference lp.cc:199-219: exact zeros are skipped, the RHS entry carries no name.
 std::string LPModel::PrintTableau() {
-  LP_ASSERT(engine_ != nullptr);
+  LP_ASSERT(HasTableau());
   const int64_t m = (int64_t)model_.constraints.size(), W = constant_index_ + 2;
   std::vector<double> T((size_t)m * W), obj(W);
-  CheckEngine(lpamd_download(engine_, T.data(), m, obj.data(), nullptr), "PrintTableau: download failed");
+  CheckEngine(group_ ? lpamd_group_download(group_.get(), T.data(), m, obj.data(), nullptr)
+                     : lpamd_download(engine_.get(), T.data(), m, obj.data(), nullptr),
+              "PrintTableau: download failed");
   auto name_of = [&](int64_t j) {
     auto it = index_to_variable_.find(j);
     return it != index_to_variable_.end() ? it->second.ToString() : Variable(kArtificial + std::to_string(std::max(0, artificial_variable_count_ - 1))).ToString();
@@ -211,7 +235,9 @@ std::string LPModel::PrintTableau() {
 
 void LPModel::SyncBasisFromEngine() {
   std::vector<uint8_t> basic(constant_index_ + 2, 0);
-  CheckEngine(lpamd_download(engine_, nullptr, 0, nullptr, basic.data()), "reading the basis flags failed");
+  CheckEngine(group_ ? lpamd_group_download(group_.get(), nullptr, 0, nullptr, basic.data())
+                     : lpamd_download(engine_.get(), nullptr, 0, nullptr, basic.data()),
+              "reading the basis flags failed");
   base_variables_.clear();
   non_base_variables_.clear();
   for (const auto& entry : index_to_variable_) (basic[entry.first] ? base_variables_ : non_base_variables_).insert(entry.second);
@@ -219,7 +245,7 @@ void LPModel::SyncBasisFromEngine() {
 
 // reference lp_simplex_tableau.cc:10-52
 void LPModel::TableauPivot(Variable base, Variable non_base, tableau_index_t constraint_id) {
-  LP_ASSERT(engine_ != nullptr);
+  LP_ASSERT(HasTableau());
   LP_ASSERT(non_base_variables_.find(non_base) != non_base_variables_.end());
   LP_ASSERT(base_variables_.find(base) != base_variables_.end());
   base_variables_.erase(base);
@@ -230,18 +256,20 @@ void LPModel::TableauPivot(Variable base, Variable non_base, tableau_index_t con
   LP_ASSERT(d != constant_index_);
   LP_ASSERT(e != constant_index_);
   LP_ASSERT(constraint_id >= 0);
-  CheckEngine(lpamd_pivot(engine_, d, e, constraint_id), "TableauPivot failed");
+  CheckEngine(group_ ? lpamd_group_pivot(group_.get(), d, e, constraint_id) : lpamd_pivot(engine_.get(), d, e, constraint_id),
+              "TableauPivot failed");
 }
 
 // reference lp_simplex_tableau.cc:64-171
 Result LPModel::TableauSimplexInitialize() {
-  LP_ASSERT(engine_ != nullptr);
+  LP_ASSERT(HasTableau());
   int32_t need = 0;
-  CheckEngine(lpamd_need_init(engine_, &need), "TableauSimplexInitialize");
+  CheckEngine(group_ ? lpamd_group_need_init(group_.get(), &need) : lpamd_need_init(engine_.get(), &need), "TableauSimplexInitialize");
   if (!need) return SOLVED;
   CreateArtificialVariable();   // the name is consumed exactly as upstream; the column itself lives at index N + 1
   int32_t result = LPAMD_ERROR;
-  CheckEngine(lpamd_phase1(engine_, (int32_t)strategy_, &result), "TableauSimplexInitialize");
+  CheckEngine(group_ ? lpamd_group_phase1(group_.get(), (int32_t)strategy_, &result) : lpamd_phase1(engine_.get(), (int32_t)strategy_, &result),
+              "TableauSimplexInitialize");
   SyncBasisFromEngine();
   if (result == LPAMD_NOSOLUTION) return NOSOLUTION;
   LP_ASSERT(result == LPAMD_SOLVED);   // upstream's live asserts (:93, :108, :111, :133, :159) abort here as well
@@ -250,9 +278,9 @@ Result LPModel::TableauSimplexInitialize() {
 
 // reference lp_simplex_tableau.cc:173-379
 Result LPModel::TableauSimplexSolve() {
-  LP_ASSERT(engine_ != nullptr);
+  LP_ASSERT(HasTableau());
   int32_t need = 0;
-  CheckEngine(lpamd_need_init(engine_, &need), "TableauSimplexSolve");
+  CheckEngine(group_ ? lpamd_group_need_init(group_.get(), &need) : lpamd_need_init(engine_.get(), &need), "TableauSimplexSolve");
   if (need) {
     Result r = TableauSimplexInitialize();
     if (r == NOSOLUTION) return NOSOLUTION;
@@ -263,7 +291,9 @@ Result LPModel::TableauSimplexSolve() {
   LP_ASSERT(strategy_ == MAX_COST || strategy_ == MAX_REDUCTION);
   int32_t result = LPAMD_ERROR;
   int64_t pivots = 0;
-  CheckEngine(lpamd_solve(engine_, (int32_t)strategy_, -1, &result, &pivots), "TableauSimplexSolve");
+  CheckEngine(group_ ? lpamd_group_solve(group_.get(), (int32_t)strategy_, -1, &result, &pivots)
+                     : lpamd_solve(engine_.get(), (int32_t)strategy_, -1, &result, &pivots),
+              "TableauSimplexSolve");
   SyncBasisFromEngine();
   if (result == LPAMD_SOLVED) {
     simplex_solution_ = GetTableauSimplexSolution();
@@ -277,9 +307,10 @@ Result LPModel::TableauSimplexSolve() {
 
 // reference lp_simplex_tableau.cc:381-410
 std::map<Variable, Num> LPModel::GetTableauSimplexSolution() {
-  LP_ASSERT(engine_ != nullptr);
+  LP_ASSERT(HasTableau());
   std::vector<double> x(constant_index_ + 2, 0.0);
-  CheckEngine(lpamd_column_values(engine_, x.data()), "GetTableauSimplexSolution");
+  CheckEngine(group_ ? lpamd_group_column_values(group_.get(), x.data()) : lpamd_column_values(engine_.get(), x.data()),
+              "GetTableauSimplexSolution");
   std::map<Variable, Num> all_sol, sol;
   for (const auto& var : non_base_variables_) {
     all_sol[var] = 0.0f;
@@ -302,9 +333,10 @@ std::map<Variable, Num> LPModel::GetTableauSimplexSolution() {
 
 // reference lp_simplex_tableau.cc:412-414
 Num LPModel::GetTableauSimplexOptimum() {
-  LP_ASSERT(engine_ != nullptr);
+  LP_ASSERT(HasTableau());
   double c = 0.0;
-  CheckEngine(lpamd_objective_constant(engine_, &c), "GetTableauSimplexOptimum");
+  CheckEngine(group_ ? lpamd_group_objective_constant(group_.get(), &c) : lpamd_objective_constant(engine_.get(), &c),
+              "GetTableauSimplexOptimum");
   return (opt_reverted_ ? -1 : 1) * c;
 }
 
@@ -321,17 +353,17 @@ Result LPModel::TableauRevisedSimplexSolve() {
   LP_ASSERT(model_.opt_obj.opt_type == OptimizationObject::MAX);
   int32_t result = LPAMD_ERROR;
   int64_t pivots = 0;
-  CheckEngine(lpamd_rev_solve(rev_engine_, -1, &result, &pivots), "TableauRevisedSimplexSolve");
+  CheckEngine(lpamd_rev_solve(rev_engine_.get(), -1, &result, &pivots), "TableauRevisedSimplexSolve");
   if (result == LPAMD_UNBOUNDED) return UNBOUNDED;
   if (result == LPAMD_NOSOLUTION) return NOSOLUTION;
   if (result != LPAMD_SOLVED) return ERROR;
   double optimum = 0.0;
-  CheckEngine(lpamd_rev_optimum(rev_engine_, &optimum), "TableauRevisedSimplexSolve");
+  CheckEngine(lpamd_rev_optimum(rev_engine_.get(), &optimum), "TableauRevisedSimplexSolve");
   revised_simplex_optimum_ = Num(optimum);
   // :259-277: basic_feasible_solution scattered over the variables, then the
   // substituted raw variables are rebuilt from their expressions.
   std::vector<double> x(constant_index_ + 2, 0.0);
-  CheckEngine(lpamd_rev_column_values(rev_engine_, x.data()), "TableauRevisedSimplexSolve");
+  CheckEngine(lpamd_rev_column_values(rev_engine_.get(), x.data()), "TableauRevisedSimplexSolve");
   std::map<Variable, Num> all_sol;
   revised_simplex_solution_.clear();
   for (const auto& entry : variable_to_index_) all_sol[entry.first] = Num(x[entry.second]);
@@ -355,10 +387,10 @@ std::map<Variable, Num> LPModel::GetTableauRevisedSimplexSolution() { return rev
 int64_t LPModel::TableauPivotCount() {
   int64_t n = 0;
   if (rev_engine_ != nullptr) {
-    CheckEngine(lpamd_rev_pivot_count(rev_engine_, &n), "TableauPivotCount");
+    CheckEngine(lpamd_rev_pivot_count(rev_engine_.get(), &n), "TableauPivotCount");
     return n;
   }
-  CheckEngine(lpamd_pivot_count(engine_, &n), "TableauPivotCount");
+  CheckEngine(group_ ? lpamd_group_pivot_count(group_.get(), &n) : lpamd_pivot_count(engine_.get(), &n), "TableauPivotCount");
   return n;
 }
 
@@ -366,8 +398,9 @@ std::vector<std::pair<int64_t, int64_t>> LPModel::TableauPivotTrace() {
   const int64_t n = TableauPivotCount();
   std::vector<int64_t> e(std::max<int64_t>(n, 1)), r(std::max<int64_t>(n, 1));
   int64_t got = 0;
-  if (rev_engine_ != nullptr) CheckEngine(lpamd_rev_trace(rev_engine_, e.data(), r.data(), n, &got), "TableauPivotTrace");
-  else CheckEngine(lpamd_trace(engine_, e.data(), r.data(), n, &got), "TableauPivotTrace");
+  if (rev_engine_ != nullptr) CheckEngine(lpamd_rev_trace(rev_engine_.get(), e.data(), r.data(), n, &got), "TableauPivotTrace");
+  else if (group_ != nullptr) CheckEngine(lpamd_group_trace(group_.get(), e.data(), r.data(), n, &got), "TableauPivotTrace");
+  else CheckEngine(lpamd_trace(engine_.get(), e.data(), r.data(), n, &got), "TableauPivotTrace");
   std::vector<std::pair<int64_t, int64_t>> out;
   for (int64_t i = 0; i < n; i++) out.emplace_back(e[i], r[i]);
   return out;

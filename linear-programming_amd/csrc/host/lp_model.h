@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <set>
 #include <string>
 #include <vector>
@@ -23,6 +24,7 @@
 
 struct lpamd_engine;
 struct lpamd_rev_engine;
+struct lpamd_group;
 
 typedef int64_t tableau_index_t;
 typedef int64_t tableau_size_t;
@@ -55,7 +57,9 @@ class LPModel {
  public:
   LPModel(Model model) : model_(model) {}
   LPModel() : model_({{}, OptimizationObject(FLOAT)}) {}
-  LPModel(const LPModel&) = default;   // copies share the device engine (reference copies share raw pointers)
+  // Copies share the device tableau, as copies of the reference's LPModel share its raw tableau pointers
+  // (reference lp.h:273-274); unlike there, the last copy to go frees it.
+  LPModel(const LPModel&) = default;
   LPModel& operator=(const LPModel&) = default;
 
   void AddConstraint(Constraint constraint) { model_.constraints.push_back(constraint); }
@@ -70,6 +74,11 @@ class LPModel {
   void ToSlackForm();
   // Builds the dense tableau and moves it into HBM (needs a GPU).
   void ToTableau(TableauStorageFormat format = ROW_AND_COLUMN);
+  // Column shards for the next ToTableau(): n_gpus > 1 deals the columns over GPUs 0..n_gpus-1 (RCCL
+  // inside the engine).  share_one_gpu keeps all shards on GPU 0 with an in-process exchange (a one-GPU
+  // machine can walk the multi-GPU code this way).  Without a call the environment variable LPAMD_GPUS
+  // decides, default 1.  The revised simplex runs on one GPU.
+  void SetGpus(int n_gpus, bool share_one_gpu = false) { n_gpus_ = n_gpus; share_one_gpu_ = share_one_gpu; }
   // The dense matrix ToTableau uploads, computed on the host only.
   HostTableau BuildHostTableau();
 
@@ -125,8 +134,13 @@ class LPModel {
   std::set<Variable> non_negative_variables_;
   std::map<Variable, Expression> raw_variable_expression_;
 
-  lpamd_rev_engine* rev_engine_ = nullptr;   // revised simplex: tableau + basis inverse on the device
-  lpamd_engine* engine_ = nullptr;     // owns the device tableau; intentionally never freed, like the reference's raw pointers
+  // Device state, shared by copies of the model and released with the last of them.
+  std::shared_ptr<lpamd_rev_engine> rev_engine_;   // revised simplex: tableau + basis inverse on one GPU
+  std::shared_ptr<lpamd_engine> engine_;           // the tableau on one GPU
+  std::shared_ptr<lpamd_group> group_;             // the tableau as column shards over several GPUs
+  int n_gpus_ = 0;                                 // 0: LPAMD_GPUS or 1
+  bool share_one_gpu_ = false;
+  bool HasTableau() const { return engine_ != nullptr || group_ != nullptr; }
   std::map<Variable, tableau_index_t> variable_to_index_;
   std::map<tableau_index_t, Variable> index_to_variable_;
   tableau_index_t constant_index_ = -1;

@@ -1,13 +1,16 @@
-// solver <input-file> [solver-algo] [pivot-strategy]
+// solver <input-file> [solver-algo] [pivot-strategy] [--gpus N | --shards K] [--time] [--trace]
 // Command line of the reference's solver.cc for the tableau path: parses the LP
 // text file, runs `simplex_tableau` or `revised_simplex_tableau` on the GPU engine
 // and prints the optimum followed by `name = value` lines (reference
 // solver.cc:123-171).  The other algorithms belong to the reference's CPU-only
 // solvers and are rejected.  A file ending in .mps is first converted the way the reference's
-// tools/mps_load.py does.
+// tools/mps_load.py does.  --gpus N deals the tableau columns over N GPUs (RCCL inside the engine;
+// LPAMD_GPUS=N does the same without touching the command line); --shards K keeps K column shards on
+// GPU 0 with an in-process exchange, which walks the same multi-GPU code on a one-GPU machine.
 #include <algorithm>
 #include <cctype>
 #include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 
@@ -36,20 +39,36 @@ bool EndsWith(const std::string& s, const std::string& suffix) {
 
 }  // namespace
 
+static int Run(int argc, char** argv);
+
 int main(int argc, char** argv) {
+  try {
+    return Run(argc, argv);
+  } catch (const std::exception& ex) {   // parser errors and engine failures (reference: uncaught std::runtime_error)
+    std::cerr << "solver: " << ex.what() << "\n";
+    return 3;
+  }
+}
+
+static int Run(int argc, char** argv) {
   if (argc < 2) {
     std::cout << "usage: " << argv[0] << " input-file [solver-algo] [pivot-strategy]\n";
     return -1;
   }
   const std::string path = argv[1];
-  const std::string algo = argc >= 3 ? Lower(argv[2]) : "simplex_tableau";
+  const bool has_algo = argc >= 3 && argv[2][0] != '-';
+  const std::string algo = has_algo ? Lower(argv[2]) : "simplex_tableau";
   LPModel::PivotingStrategy strategy = LPModel::MAX_COST;
-  if (argc >= 4) strategy = ParsePivotingStrategy(argv[3]);
+  if (has_algo && argc >= 4 && argv[3][0] != '-') strategy = ParsePivotingStrategy(argv[3]);
   bool print_trace = false;
   bool print_time = false;   // --time: wall time of the solve call and its pivot count on stderr (stdout stays the reference's)
-  for (int i = 4; i < argc; i++) {
-    print_trace |= std::string(argv[i]) == "--trace";
-    print_time |= std::string(argv[i]) == "--time";
+  int n_gpus = 0, n_shards = 0;
+  for (int i = 2; i < argc; i++) {
+    const std::string a = argv[i];
+    print_trace |= a == "--trace";
+    print_time |= a == "--time";
+    if (a == "--gpus" && i + 1 < argc) n_gpus = std::atoi(argv[++i]);
+    else if (a == "--shards" && i + 1 < argc) n_shards = std::atoi(argv[++i]);
   }
 
   Parser parser;
@@ -74,6 +93,8 @@ int main(int argc, char** argv) {
 
   LPModel lp_model(model);
   lp_model.SetPivotingStrategy(strategy);
+  if (n_shards > 1) lp_model.SetGpus(n_shards, true);
+  else if (n_gpus > 0) lp_model.SetGpus(n_gpus);
   lp_model.ToStandardForm();
   lp_model.ToSlackForm();
   Result result = ERROR;

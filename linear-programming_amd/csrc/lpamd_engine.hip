@@ -542,10 +542,15 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
 // Device-resident main loop: at most `budget` pivots (budget < 0: none).
 int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   LP_TRY(pull_state(e));
+  if (budget == 0) { *result = LPAMD_LIMIT; return LPAMD_OK; }   // nothing to enqueue: the budget is spent before the first pivot
   e->h_st.status = ST_RUNNING;
   e->h_st.max_iter = budget < 0 ? std::numeric_limits<int64_t>::max() : e->h_st.iter + budget;
   e->h_st.n_active = e->h_st.n_active2 = 0;   // both counter slots of the two-launch loop start empty
   LP_TRY(push_state(e));
+  // A run that ended on a terminal status may have left other data in the partial buffers (the set-up kernel is a
+  // no-op then, max-reduction pricing shares the buffers): every run prices its first iteration afresh.
+  e->price_partials_fresh = false;
+  e->price_buf = 0;
   e->slot_counter = 0;
   struct RestorePriceBuf {   // every other path keeps the pricing partials in the first half
     lpamd_engine* e;
@@ -878,6 +883,7 @@ static int begin_step(lpamd_engine* e) {
   e->h_st.status = ST_RUNNING;
   e->h_st.max_iter = std::numeric_limits<int64_t>::max();
   e->h_st.n_active = 0;
+  e->price_partials_fresh = false;
   return push_state(e);
 }
 
@@ -1165,8 +1171,8 @@ int lpamd_set_profiling(lpamd_engine* e, int32_t on) {
   return LPAMD_OK;
 }
 
-int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int64_t* active_columns) {
-  CHECK_ENGINE(e);
+// Folds the HIP events recorded since the last call into the running totals.
+static int drain_events(lpamd_engine* e) {
   HIP_TRY(hipStreamSynchronize(e->stream));
   for (size_t k = 0; k + 1 < e->ev_used; k += 2) {
     float ms = 0.f;
@@ -1175,6 +1181,12 @@ int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int
     e->prof_launches++;
   }
   e->ev_used = 0;
+  return LPAMD_OK;
+}
+
+int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int64_t* active_columns) {
+  CHECK_ENGINE(e);
+  LP_TRY(drain_events(e));
   LP_TRY(pull_state(e));
   e->prof_active = e->h_st.n_active;
   if (e->loop_depth > 1) {   // a pass that applied several pivots counts the columns of each
@@ -1187,6 +1199,32 @@ int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int
   if (total_ms) *total_ms = e->prof_ms;
   if (launches) *launches = e->prof_launches;
   if (active_columns) *active_columns = e->prof_active;
+  return LPAMD_OK;
+}
+
+int lpamd_profile_totals(lpamd_engine* e, double* total_ms, int64_t* passes, int64_t* pivots, int64_t* streamed_columns,
+                         int64_t* touched_columns) {
+  CHECK_ENGINE(e);
+  LP_TRY(drain_events(e));
+  LP_TRY(pull_state(e));
+  int64_t np = e->prof_launches, nv = e->prof_launches;
+  int64_t streamed = e->prof_launches * (int64_t)e->h_st.n_active, touched = streamed;   // one pivot per pass
+  if (e->loop_depth > 1) {   // chained passes keep their totals on the device (record 0 of the step array)
+    ChainStep c0;
+    LP_TRY(read_local(e, e->steps, &c0, sizeof(c0)));
+    np = c0.r; nv = (int64_t)c0.a; streamed = c0.d; touched = c0.e;
+  }
+  if (total_ms) *total_ms = e->prof_ms;
+  if (passes) *passes = np;
+  if (pivots) *pivots = nv;
+  if (streamed_columns) *streamed_columns = streamed;
+  if (touched_columns) *touched_columns = touched;
+  return LPAMD_OK;
+}
+
+int lpamd_loop_depth(const lpamd_engine* e, int32_t strategy, int32_t* depth) {
+  if (!e || !depth) return set_err(LPAMD_E_ARG, "loop_depth: null argument");
+  *depth = (strategy == LPAMD_MAX_COST && !e->two_launch) ? e->chain_depth : 1;
   return LPAMD_OK;
 }
 
@@ -1291,6 +1329,7 @@ int lpamd_set_pivot_budget(lpamd_engine* e, int64_t max_pivots) {
   LP_TRY(pull_state(e));
   e->h_st.status = ST_RUNNING;
   e->h_st.max_iter = max_pivots < 0 ? std::numeric_limits<int64_t>::max() : e->h_st.iter + max_pivots;
+  e->price_partials_fresh = false;
   return push_state(e);
 }
 
@@ -1390,3 +1429,4 @@ int lpamd_poll(lpamd_engine* e, int32_t* result) {
 }  // extern "C"
 
 #include "lpamd_revised.hip.h"
+#include "lpamd_sharded.hip.h"

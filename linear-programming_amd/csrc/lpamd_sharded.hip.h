@@ -1,0 +1,842 @@
+// Column shards over several GPUs behind the C ABI (lpamd_group_* in include/lpamd.h).
+//
+// A group is one LP whose tableau columns are dealt round-robin over `world` shards, one
+// lpamd_engine per shard (see lpamd_engine.hip).  Two ways to run it:
+//   - one process drives several GPUs: one host thread and one RCCL communicator per shard
+//     (ncclCommInitAll); this is what `solver --gpus N` and LPModel use;
+//   - one process per GPU (torch.distributed.run, MPI, ...): every process holds one shard
+//     and joins the communicator with an id that the caller delivers (ncclCommInitRank).
+// RCCL is loaded on first use (dlopen), so single-GPU users never pay for it.
+//
+// The pivot loop needs ONE collective per pivot: every rank packs its best local candidate,
+// the 32-byte record and the candidate COLUMN itself (as the pivots set up so far will leave
+// it), into its slot; an all-gather hands every rank all slots; every rank folds the records
+// with the reference's tie-break (reference lp_simplex_tableau.cc:188-198 / 310-325: larger
+// key, lowest global column on ties) and reads the winner's column from the winner's slot.
+// Sending a column that may lose costs bandwidth (world * 8 * m bytes per pivot, 2 MiB at
+// m = 32768 over 8 ranks) and saves the second, dependent collective; both are latency-bound.
+// Everything else (ratio test on the RHS replica, row gather, rank-1 update) is rank-local
+// and bit-identical across ranks.
+//
+// LPAMD_GROUP_LOCAL_EXCHANGE replaces RCCL by device copies between the shards of one process
+// (events + host barriers).  It exists so that several shards can share ONE GPU, which RCCL
+// refuses, for tests on a one-GPU machine; it also works across GPUs with peer access.
+#pragma once
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only; the symbols are resolved with dlsym
+
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+
+namespace lpamd {
+
+constexpr int kSlotHeaderWords = 8;   // 64 bytes: the candidate record (32 B) and padding
+
+// In-order loop (MAX_REDUCTION): the local candidate record and its column as stored.
+__global__ __launch_bounds__(256) void k_export_candidate(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const Candidate* __restrict__ cand, uint64_t* __restrict__ slot) {
+  if (st->status != ST_RUNNING) return;
+  const Candidate c = *cand;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<Candidate*>(slot) = c;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sh.lda) return;
+  double v = 0.0;
+  if (c.gcol >= 0) {
+    const int64_t eo = ordinal_of(c.gcol, sh.N);
+    if (eo % sh.world == sh.rank) v = T.col(eo / sh.world)[i];
+  }
+  reinterpret_cast<double*>(slot + kSlotHeaderWords)[i] = v;
+}
+
+// Fold of the gathered slots.  kInOrder: the fold of the in-order loop, which also settles the
+// status (budget, optimum, unbounded; reference lp_simplex_tableau.cc:201-205, 230-233, 365-373)
+// and keeps the winner in the engine's own candidate.  Otherwise (look-ahead loop): runs next to
+// the rank-1 update, touches no pivot state; "no candidate" travels as gcol = -1.
+template <bool kInOrder>
+__global__ __launch_bounds__(256) void k_pick_winner(
+    const uint64_t* __restrict__ slots, int world, int64_t slot_words, Shape sh, int max_reduction,
+    PivotState* __restrict__ st, Candidate* __restrict__ cand_out, double* __restrict__ xbuf) {
+  __shared__ int s_w;
+  if (kInOrder && st->status != ST_RUNNING) return;
+  if (threadIdx.x == 0) {
+    Candidate best;
+    best.key = -DBL_MAX; best.gcol = -1; best.row = -1; best.ce = 0.0;
+    int w = -1;
+    bool any = false;
+    for (int k = 0; k < world; k++) {
+      const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)k * slot_words);
+      if (c.gcol < 0) continue;
+      any = true;
+      if (max_reduction && c.row < 0) continue;
+      if (best.gcol < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) { best = c; w = k; }
+    }
+    s_w = w;
+    if (blockIdx.x == 0) {
+      if (kInOrder) {
+        if (st->iter >= st->max_iter) st->status = ST_LIMIT;
+        else if (w < 0) st->status = any ? ST_UNBOUNDED : ST_SOLVED;
+        else *cand_out = best;
+      } else {
+        *cand_out = best;
+      }
+    }
+  }
+  __syncthreads();
+  const int w = s_w;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < sh.lda) xbuf[i] = w >= 0 ? reinterpret_cast<const double*>(slots + (size_t)w * slot_words + kSlotHeaderWords)[i] : 0.0;
+}
+
+// out[i] = sum over ranks of stage[k][i] as 64-bit integers: with at most one non-zero
+// contribution per word this hands every rank the exact bit pattern.
+__global__ __launch_bounds__(256) void k_sum_words(const uint64_t* __restrict__ stage, int world, int64_t words, uint64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= words) return;
+  uint64_t s = 0;
+  for (int k = 0; k < world; k++) s += stage[(size_t)k * words + i];
+  out[i] = s;
+}
+
+}  // namespace lpamd
+
+namespace {
+
+// ---- RCCL, resolved on first use -------------------------------------------------------
+struct RcclApi {
+  void* so = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommInitAll) CommInitAll = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+std::mutex g_rccl_mutex;
+RcclApi g_rccl;
+
+int rccl_api(RcclApi** out) {
+  std::lock_guard<std::mutex> lock(g_rccl_mutex);
+  if (!g_rccl.so) {
+    // a copy that the process already holds (e.g. the one PyTorch ships) is found by its soname
+    const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    void* so = nullptr;
+    for (const char* n : names)
+      if ((so = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!so) return set_err(LPAMD_E_UNSUPPORTED, "RCCL is not available: %s", dlerror());
+    RcclApi a;
+    a.so = so;
+#define LPAMD_RCCL_SYM(field, name)                                                       \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(so, name));                         \
+  if (!a.field) return set_err(LPAMD_E_UNSUPPORTED, "RCCL symbol %s is missing", name)
+    LPAMD_RCCL_SYM(GetUniqueId, "ncclGetUniqueId");
+    LPAMD_RCCL_SYM(CommInitRank, "ncclCommInitRank");
+    LPAMD_RCCL_SYM(CommInitAll, "ncclCommInitAll");
+    LPAMD_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    LPAMD_RCCL_SYM(AllGather, "ncclAllGather");
+    LPAMD_RCCL_SYM(GetErrorString, "ncclGetErrorString");
+#undef LPAMD_RCCL_SYM
+    g_rccl = a;
+  }
+  *out = &g_rccl;
+  return LPAMD_OK;
+}
+
+#define RCCL_TRY(api, expr)                                                                              \
+  do {                                                                                                   \
+    ncclResult_t _r = (expr);                                                                            \
+    if (_r != ncclSuccess) return set_err(LPAMD_E_HIP, "%s failed: %s", #expr, (api)->GetErrorString(_r)); \
+  } while (0)
+
+// ---- host barrier of the in-process exchange -------------------------------------------
+class HostBarrier {
+ public:
+  void reset(int n) { n_ = n; waiting_ = 0; phase_ = 0; broken_ = false; }
+  // false: another shard failed and the barrier was broken
+  bool wait() {
+    std::unique_lock<std::mutex> lock(mu_);
+    if (broken_) return false;
+    const uint64_t phase = phase_;
+    if (++waiting_ == n_) {
+      waiting_ = 0;
+      phase_++;
+      cv_.notify_all();
+      return true;
+    }
+    cv_.wait(lock, [&] { return phase_ != phase || broken_; });
+    return !broken_;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lock(mu_);
+    broken_ = true;
+    cv_.notify_all();
+  }
+ private:
+  std::mutex mu_;
+  std::condition_variable cv_;
+  int n_ = 1, waiting_ = 0;
+  uint64_t phase_ = 0;
+  bool broken_ = false;
+};
+
+}  // namespace
+
+struct lpamd_shard {   // one column shard of a group and its exchange state
+  lpamd_engine* eng = nullptr;
+  int device = 0;
+  int rank = 0;
+  hipStream_t xstream = nullptr;             // exchange stream: the collective of the next pass runs beside the update
+  hipEvent_t ev_sent = nullptr, ev_arrived = nullptr;
+  hipEvent_t ev_pub = nullptr, ev_read = nullptr;   // in-process exchange
+  ncclComm_t comm = nullptr;
+  uint64_t* slot = nullptr;                  // kSlotHeaderWords + lda words: what this rank sends
+  uint64_t* slots = nullptr;                 // world slots: what every rank receives
+  double* xbuf = nullptr;                    // lda doubles: the entering column of the pivot being set up
+  uint64_t* send = nullptr;                  // assembly of rows / columns / objective: max(N + 2, lda) words ...
+  uint64_t* stage = nullptr;                 // ... world blocks of them ...
+  uint64_t* summed = nullptr;                // ... and their exact sum
+  int rc = LPAMD_OK;
+  std::string err;
+};
+
+struct lpamd_group {
+  int64_t m = 0, N = 0, lda = 0, slot_words = 0, wide = 0;
+  int world = 1;
+  bool local_exchange = false;
+  bool inline_exchange = true;    // collectives inside a chain run on the engine's stream (nothing to overlap them with)
+  int chain = 1;                  // pivots per pass of the look-ahead loop
+  int poll_every = 64;
+  std::vector<lpamd_shard> shards;           // the shards this process holds
+  std::vector<const void*> pub;              // in-process exchange: what every rank offers
+  HostBarrier barrier;
+};
+
+namespace {
+
+using Group = lpamd_group;
+using Shard = lpamd_shard;
+
+// Runs fn on every local shard, one host thread per shard when there are several (the loops
+// are collective: all shards must be inside them at the same time).  The first failure wins.
+template <typename Fn>
+int for_each_shard(Group* g, Fn fn) {
+  if (g->shards.size() == 1) {
+    Shard& s = g->shards[0];
+    HIP_TRY(hipSetDevice(s.device));
+    return fn(s);
+  }
+  g->barrier.reset((int)g->shards.size());
+  std::vector<std::thread> threads;
+  for (Shard& s : g->shards) {
+    s.rc = LPAMD_OK;
+    s.err.clear();
+    threads.emplace_back([g, &s, &fn] {
+      if (hipSetDevice(s.device) != hipSuccess) s.rc = set_err(LPAMD_E_HIP, "hipSetDevice(%d) failed", s.device);
+      else s.rc = fn(s);
+      if (s.rc != LPAMD_OK) {
+        s.err = g_err;            // g_err is per thread
+        g->barrier.abort();       // nobody waits for a shard that gave up
+      }
+    });
+  }
+  for (std::thread& t : threads) t.join();
+  for (Shard& s : g->shards)
+    if (s.rc != LPAMD_OK) return set_err(s.rc, "shard %d: %s", s.rank, s.err.c_str());
+  return LPAMD_OK;
+}
+
+// All-gather of `words` 64-bit words per rank on `stream` (send and recv are device memory).
+int all_gather_words(Group* g, Shard& s, const uint64_t* send, uint64_t* recv, int64_t words, hipStream_t stream) {
+  if (!g->local_exchange) {
+    RcclApi* api = nullptr;
+    LP_TRY(rccl_api(&api));
+    RCCL_TRY(api, api->AllGather(send, recv, (size_t)words, ncclUint64, s.comm, stream));
+    return LPAMD_OK;
+  }
+  // In-process exchange: publish, wait until everybody has published, copy every rank's block,
+  // wait until everybody has copied (the caller may overwrite `send` afterwards).
+  g->pub[s.rank] = send;
+  HIP_TRY(hipEventRecord(s.ev_pub, stream));
+  if (g->shards.size() > 1 && !g->barrier.wait()) return set_err(LPAMD_E_STATE, "another shard failed");
+  for (Shard& q : g->shards) {
+    HIP_TRY(hipStreamWaitEvent(stream, q.ev_pub, 0));
+    HIP_TRY(hipMemcpyAsync(recv + (size_t)q.rank * words, g->pub[q.rank], sizeof(uint64_t) * words, hipMemcpyDeviceToDevice, stream));
+  }
+  HIP_TRY(hipEventRecord(s.ev_read, stream));
+  if (g->shards.size() > 1 && !g->barrier.wait()) return set_err(LPAMD_E_STATE, "another shard failed");
+  for (Shard& q : g->shards) HIP_TRY(hipStreamWaitEvent(stream, q.ev_read, 0));
+  return LPAMD_OK;
+}
+
+// Every rank gets the element-wise exact sum of the ranks' host vectors (n doubles; at most
+// one rank contributes a non-zero bit pattern per entry).  Synchronises.
+int sum_exact(Group* g, Shard& s, double* vec, int64_t n) {
+  hipStream_t st = s.eng->stream;
+  HIP_TRY(hipMemcpyAsync(s.send, vec, sizeof(double) * n, hipMemcpyHostToDevice, st));
+  LP_TRY(all_gather_words(g, s, s.send, s.stage, n, st));
+  hipLaunchKernelGGL(k_sum_words, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, s.stage, g->world, n, s.summed);
+  LP_TRY(check_launch("k_sum_words"));
+  HIP_TRY(hipMemcpyAsync(vec, s.summed, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return LPAMD_OK;
+}
+
+// Full N + 2 vector from per-rank vectors that hold the local columns only; the replicated
+// right-hand-side entry is taken from rank 0.
+int assemble(Group* g, Shard& s, std::vector<double>& v) {
+  if (s.rank != 0) v[g->N] = 0.0;
+  return sum_exact(g, s, v.data(), g->N + 2);
+}
+int assembled_row(Group* g, Shard& s, int64_t r, std::vector<double>& row) {
+  std::fill(row.begin(), row.end(), 0.0);
+  LP_TRY(lpamd_read_row(s.eng, r, row.data()));
+  return assemble(g, s, row);
+}
+int assembled_objective(Group* g, Shard& s, std::vector<double>& obj) {
+  std::fill(obj.begin(), obj.end(), 0.0);
+  LP_TRY(lpamd_download(s.eng, nullptr, 0, obj.data(), nullptr));
+  return assemble(g, s, obj);
+}
+int assembled_basic(Group* g, Shard& s, std::vector<uint8_t>& basic) {
+  std::vector<uint8_t> b(g->N + 2, 0);
+  LP_TRY(lpamd_download(s.eng, nullptr, 0, nullptr, b.data()));
+  std::vector<double> v(g->N + 2, 0.0);
+  for (int64_t j = 0; j < g->N + 2; j++) v[j] = (j != g->N && owns(s.eng, j) && b[j]) ? 1.0 : 0.0;
+  LP_TRY(sum_exact(g, s, v.data(), g->N + 2));
+  for (int64_t j = 0; j < g->N + 2; j++) basic[j] = v[j] != 0.0 ? 1 : 0;
+  return LPAMD_OK;
+}
+// Column `col` on every rank (read by its owner).
+int assembled_column(Group* g, Shard& s, int64_t col, std::vector<double>& out) {
+  if (col == g->N) return lpamd_read_column(s.eng, col, out.data());
+  std::fill(out.begin(), out.end(), 0.0);
+  if (owns(s.eng, col)) LP_TRY(lpamd_read_column(s.eng, col, out.data()));
+  return sum_exact(g, s, out.data(), g->m);
+}
+
+// LPModel::TableauPivot(d -> out, e -> in, row r) on every shard (reference lp_simplex_tableau.cc:10-52):
+// the owner of column e offers it, everybody else zeros; the exact sum lands in xbuf.
+int pivot_shards(Group* g, Shard& s, int64_t d, int64_t e, int64_t r, double ce) {
+  hipStream_t st = s.eng->stream;
+  if (owns(s.eng, e)) HIP_TRY(hipMemcpyAsync(s.send, s.eng->T.col(local_of(s.eng, e)), sizeof(double) * g->lda, hipMemcpyDeviceToDevice, st));
+  else HIP_TRY(hipMemsetAsync(s.send, 0, sizeof(double) * g->lda, st));
+  LP_TRY(all_gather_words(g, s, s.send, s.stage, g->lda, st));
+  hipLaunchKernelGGL(k_sum_words, dim3((unsigned)((g->lda + 255) / 256)), dim3(256), 0, st, s.stage, g->world, g->lda,
+                     reinterpret_cast<uint64_t*>(s.xbuf));
+  LP_TRY(check_launch("k_sum_words"));
+  return lpamd_pivot_shard(s.eng, d, e, r, ce, s.xbuf);
+}
+
+// ---- the pivot loops ----------------------------------------------------------------------
+// Exchange for the NEXT pivot: gather the slots, keep the winner, deliver its column.  on_x: on
+// the exchange stream, ordered after what the engine's stream holds so far (the export) and beside
+// what it gets next (the update); otherwise in line on the engine's stream.
+int exchange_lookahead(Group* g, Shard& s, bool on_x) {
+  lpamd_engine* e = s.eng;
+  hipStream_t st = on_x ? s.xstream : e->stream;
+  if (on_x) {
+    HIP_TRY(hipEventRecord(s.ev_sent, e->stream));
+    HIP_TRY(hipStreamWaitEvent(s.xstream, s.ev_sent, 0));
+  }
+  LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, st));
+  hipLaunchKernelGGL(k_pick_winner<false>, dim3((unsigned)((g->lda + 255) / 256)), dim3(256), 0, st, s.slots, g->world, g->slot_words,
+                     e->sh, 0, e->st, e->cand_la, s.xbuf);
+  LP_TRY(check_launch("k_pick_winner"));
+  if (on_x) HIP_TRY(hipEventRecord(s.ev_arrived, s.xstream));
+  return LPAMD_OK;
+}
+
+int export_lookahead(Shard& s) {
+  return lpamd_lookahead_export(s.eng, s.slot, s.slot + kSlotHeaderWords);
+}
+
+// MAX_COST: look-ahead exchange and chains of pivots per pass (see lpamd.h, lpamd_lookahead_* and
+// lpamd_chain_step).  Per pass: set-up of the first pivot on the column the previous exchange
+// delivered; chain - 1 times {export, exchange, lpamd_chain_step}; export + exchange of the next
+// pass's first pivot on the exchange stream while the pass streams the shard.
+int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done) {
+  lpamd_engine* e = s.eng;
+  int64_t start = 0;
+  LP_TRY(lpamd_pivot_count(e, &start));
+  if (k == 0) { *result = LPAMD_LIMIT; *done = 0; return LPAMD_OK; }
+  LP_TRY(lpamd_set_pivot_budget(e, k));
+  LP_TRY(export_lookahead(s));                 // nothing pending: the column as stored
+  LP_TRY(exchange_lookahead(g, s, true));
+  int64_t enqueued = 0;
+  int32_t res = LPAMD_LIMIT;
+  for (;;) {
+    const int64_t n = k < 0 ? g->poll_every : std::min<int64_t>(g->poll_every, k - enqueued);
+    const int64_t passes = (n + g->chain - 1) / g->chain;
+    for (int64_t p = 0; p < passes; p++) {
+      HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));
+      LP_TRY(lpamd_lookahead_setup(e, s.xbuf));
+      for (int j = 1; j < g->chain; j++) {
+        LP_TRY(export_lookahead(s));
+        LP_TRY(exchange_lookahead(g, s, !g->inline_exchange));
+        if (!g->inline_exchange) HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));
+        LP_TRY(lpamd_chain_step(e, s.xbuf));
+      }
+      LP_TRY(export_lookahead(s));             // next candidate, as the pending pass will leave it ...
+      LP_TRY(exchange_lookahead(g, s, true));  // ... travels while ...
+      LP_TRY(lpamd_lookahead_update(e));       // ... the pass streams the shard
+    }
+    enqueued += passes * g->chain;
+    LP_TRY(lpamd_poll(e, &res));
+    if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
+  }
+  HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));   // the last exchange is not consumed; keep the streams ordered
+  HIP_TRY(hipStreamSynchronize(e->stream));
+  int64_t now = 0;
+  LP_TRY(lpamd_pivot_count(e, &now));
+  *result = res;
+  *done = now - start;
+  return LPAMD_OK;
+}
+
+// MAX_REDUCTION (and any strategy without look-ahead): pricing, ONE all-gather of record + column,
+// fold, pivot; no host round trip inside a batch.
+int run_in_order(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
+  lpamd_engine* e = s.eng;
+  int64_t start = 0;
+  LP_TRY(lpamd_pivot_count(e, &start));
+  if (k == 0) { *result = LPAMD_LIMIT; *done = 0; return LPAMD_OK; }
+  LP_TRY(lpamd_set_pivot_budget(e, k));
+  int64_t enqueued = 0;
+  int32_t res = LPAMD_LIMIT;
+  Candidate* local = reinterpret_cast<Candidate*>(s.send);   // this rank's record before it is packed into the slot
+  for (;;) {
+    const int64_t n = k < 0 ? g->poll_every : std::min<int64_t>(g->poll_every, k - enqueued);
+    for (int64_t i = 0; i < n; i++) {
+      LP_TRY(lpamd_local_candidate(e, strategy, local));
+      hipLaunchKernelGGL(k_export_candidate, dim3((unsigned)((g->lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->sh, e->st, local, s.slot);
+      LP_TRY(check_launch("k_export_candidate"));
+      LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
+      hipLaunchKernelGGL(k_pick_winner<true>, dim3((unsigned)((g->lda + 255) / 256)), dim3(256), 0, e->stream, s.slots, g->world,
+                         g->slot_words, e->sh, strategy == LPAMD_MAX_REDUCTION ? 1 : 0, e->st, e->cand, s.xbuf);
+      LP_TRY(check_launch("k_pick_winner"));
+      LP_TRY(lpamd_apply_pivot(e, strategy, -1, -1, s.xbuf));
+    }
+    enqueued += n;
+    LP_TRY(lpamd_poll(e, &res));
+    if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
+  }
+  int64_t now = 0;
+  LP_TRY(lpamd_pivot_count(e, &now));
+  *result = res;
+  *done = now - start;
+  return LPAMD_OK;
+}
+
+int run_pivots_shard(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
+  if (strategy == LPAMD_MAX_COST) return run_lookahead(g, s, k, result, done);
+  if (strategy == LPAMD_MAX_REDUCTION) return run_in_order(g, s, strategy, k, result, done);
+  return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+}
+
+// LPModel::TableauSimplexInitialize over the shards (reference lp_simplex_tableau.cc:64-171).  The
+// scans of that phase look at single rows, columns and the objective row; every rank assembles
+// them with exact sums, takes the same decisions on the same data and applies the same explicit
+// pivots to its shard.  The inner solve is the device-resident loop above.
+int phase1_shard(Group* g, Shard& s, int32_t strategy, int32_t* result) {
+  lpamd_engine* e = s.eng;
+  const int64_t m = g->m, N = g->N, A = N + 1, W = N + 2;
+  int32_t need = 0;
+  LP_TRY(lpamd_need_init(e, &need));
+  if (!need) { *result = LPAMD_SOLVED; return LPAMD_OK; }
+  *result = LPAMD_ERROR;
+  std::vector<double> saved(W, 0.0), tmp(W, 0.0), col(m), row(W, 0.0), obj_now(W, 0.0);
+  std::vector<uint8_t> basic(W, 0);
+  LP_TRY(assembled_objective(g, s, saved));
+  tmp[A] = -1.0;                                                       // :79
+  LP_TRY(lpamd_write_objective(e, tmp.data()));
+  LP_TRY(lpamd_set_basic_flag(e, A, 0));                               // :71
+  LP_TRY(lpamd_fill_column(e, A, 1.0));                                // :82-86
+  LP_TRY(lpamd_read_column(e, N, col.data()));
+  int64_t r = -1;
+  double mv = 0.0;
+  for (int64_t i = 0; i < m; i++)                                      // MinReduce, ties to the later row (:88-91)
+    if (!(mv < col[i])) { mv = col[i]; r = i; }
+  if (r < 0) return LPAMD_OK;
+  LP_TRY(assembled_row(g, s, r, row));
+  LP_TRY(assembled_basic(g, s, basic));
+  int64_t d = -1;
+  for (int64_t j = 0; j < W; j++) {                                    // :94-104
+    if (j == N || h_is_zero(row[j])) continue;
+    if (basic[j]) { d = j; break; }
+  }
+  if (d < 0) return LPAMD_OK;
+  LP_TRY(pivot_shards(g, s, d, A, r, tmp[A]));
+  LP_TRY(lpamd_read_column(e, N, col.data()));
+  for (int64_t i = 0; i < m; i++)                                      // :106-108 (live assert upstream)
+    if (!h_is_nonneg(col[i])) return LPAMD_OK;
+  int32_t inner = LPAMD_ERROR;
+  int64_t inner_done = 0;
+  LP_TRY(run_pivots_shard(g, s, strategy, -1, &inner, &inner_done));   // :110
+  if (inner != LPAMD_SOLVED) return LPAMD_OK;                          // :111 (live assert upstream)
+  double oc = 0.0;
+  LP_TRY(lpamd_objective_constant(e, &oc));
+  if (h_is_neg(oc)) { *result = LPAMD_NOSOLUTION; return LPAMD_OK; }   // :113-115
+  LP_TRY(assembled_basic(g, s, basic));
+  if (basic[A]) {                                                      // :117-135
+    LP_TRY(assembled_column(g, s, A, col));
+    bool pivoted = false;
+    for (int64_t i = 0; i < m && !pivoted; i++) {
+      if (h_is_zero(col[i])) continue;
+      LP_TRY(assembled_row(g, s, i, row));
+      for (int64_t j = 0; j < W; j++) {
+        if (j != N && basic[j]) continue;
+        if (h_is_zero(row[j])) continue;
+        if (j == N) return LPAMD_OK;   // upstream would pivot on the constant column and abort on its assert
+        LP_TRY(assembled_objective(g, s, obj_now));
+        LP_TRY(pivot_shards(g, s, A, j, i, obj_now[j]));
+        pivoted = true;
+        break;
+      }
+    }
+    if (!pivoted) return LPAMD_OK;
+    LP_TRY(lpamd_set_basic_flag(e, A, 0));
+    LP_TRY(assembled_basic(g, s, basic));
+  }
+  LP_TRY(lpamd_fill_column(e, A, 0.0));                                // :143
+  saved[A] = 0.0;
+  std::vector<double> acc(W, 0.0);                                     // objective re-expression (:149-166)
+  for (int64_t j = 0; j < W; j++) {
+    if (j == N || !basic[j] || h_is_zero(saved[j])) continue;
+    LP_TRY(assembled_column(g, s, j, col));
+    int64_t rho = -1;
+    double bv = (double)1e-6f;                                         // MaxAbsReduce init {-1, kEpsilonF}
+    for (int64_t i = 0; i < m; i++)
+      if (!(std::fabs(bv) > std::fabs(col[i]))) { bv = col[i]; rho = i; }
+    if (rho < 0) return LPAMD_OK;
+    LP_TRY(assembled_row(g, s, rho, row));
+    const double sc = -saved[j] / row[j];                              // :162
+    for (int64_t q = 0; q < W; q++) {
+      const double prod = row[q] * sc;
+      acc[q] = h_flushz(acc[q] + prod);
+    }
+  }
+  for (int64_t q = 0; q < W; q++) saved[q] = h_flushz(saved[q] + acc[q]);   // :166
+  LP_TRY(lpamd_write_objective(e, saved.data()));
+  *result = LPAMD_SOLVED;
+  return LPAMD_OK;
+}
+
+// LPModel::TableauSimplexSolve over the shards (reference lp_simplex_tableau.cc:173-379)
+int solve_shard(Group* g, Shard& s, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots) {
+  lpamd_engine* e = s.eng;
+  int32_t need = 0;
+  LP_TRY(lpamd_need_init(e, &need));
+  if (need) {                                                          // :174-178
+    int32_t r1 = LPAMD_ERROR;
+    LP_TRY(phase1_shard(g, s, strategy, &r1));
+    if (r1 != LPAMD_SOLVED) {
+      *result = r1 == LPAMD_NOSOLUTION ? LPAMD_NOSOLUTION : LPAMD_ERROR;
+      return lpamd_pivot_count(e, n_pivots);
+    }
+    LP_TRY(lpamd_need_init(e, &need));
+    if (need) { *result = LPAMD_ERROR; return lpamd_pivot_count(e, n_pivots); }   // :179
+  }
+  int64_t done = 0;
+  LP_TRY(run_pivots_shard(g, s, strategy, max_pivots, result, &done));
+  return lpamd_pivot_count(e, n_pivots);
+}
+
+void destroy_shard(Group* g, Shard& s) {
+  (void)hipSetDevice(s.device);
+  if (s.eng && s.eng->stream) (void)hipStreamSynchronize(s.eng->stream);
+  if (s.xstream) (void)hipStreamSynchronize(s.xstream);
+  if (s.comm) {
+    RcclApi* api = nullptr;
+    if (rccl_api(&api) == LPAMD_OK) (void)api->CommDestroy(s.comm);
+  }
+  for (hipEvent_t ev : {s.ev_sent, s.ev_arrived, s.ev_pub, s.ev_read})
+    if (ev) (void)hipEventDestroy(ev);
+  if (s.xstream) (void)hipStreamDestroy(s.xstream);
+  for (void* p : {(void*)s.slot, (void*)s.slots, (void*)s.xbuf, (void*)s.send, (void*)s.stage, (void*)s.summed})
+    if (p) (void)hipFree(p);
+  if (s.eng) lpamd_destroy(s.eng);
+  s = Shard();
+  (void)g;
+}
+
+int init_shard(Group* g, Shard& s, int rank, int device) {
+  s.rank = rank;
+  s.device = device;
+  HIP_TRY(hipSetDevice(device));
+  LP_TRY(lpamd_create(&s.eng, g->m, g->N, rank, g->world, nullptr));
+  HIP_TRY(hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking));
+  for (hipEvent_t* ev : {&s.ev_sent, &s.ev_arrived, &s.ev_pub, &s.ev_read}) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+  HIP_TRY(hipMalloc(&s.slot, sizeof(uint64_t) * g->slot_words));
+  HIP_TRY(hipMalloc(&s.slots, sizeof(uint64_t) * g->slot_words * g->world));
+  HIP_TRY(hipMalloc(&s.xbuf, sizeof(double) * g->lda));
+  HIP_TRY(hipMalloc(&s.send, sizeof(uint64_t) * g->wide));
+  HIP_TRY(hipMalloc(&s.stage, sizeof(uint64_t) * g->wide * g->world));
+  HIP_TRY(hipMalloc(&s.summed, sizeof(uint64_t) * g->wide));
+  HIP_TRY(hipMemset(s.slot, 0, sizeof(uint64_t) * g->slot_words));
+  HIP_TRY(hipMemset(s.slots, 0, sizeof(uint64_t) * g->slot_words * g->world));
+  HIP_TRY(hipMemset(s.xbuf, 0, sizeof(double) * g->lda));
+  HIP_TRY(hipMemset(s.send, 0, sizeof(uint64_t) * g->wide));
+  return LPAMD_OK;
+}
+
+Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
+  Group* g = new Group();
+  g->m = m;
+  g->N = N;
+  g->world = world;
+  g->lda = lpamd_exchange_bytes(m) / (int64_t)sizeof(double);
+  if (const char* env = getenv("LPAMD_LDA_PAD")) g->lda += round_up(std::max(0, atoi(env)), kSlabRows);
+  g->slot_words = kSlotHeaderWords + g->lda;
+  g->wide = std::max<int64_t>(N + 2, g->lda);
+  g->local_exchange = (flags & LPAMD_GROUP_LOCAL_EXCHANGE) != 0;
+  g->pub.assign(world, nullptr);
+  if (const char* env = getenv("LPAMD_SHARD_INLINE")) g->inline_exchange = atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_SHARD_POLL")) g->poll_every = std::max(1, atoi(env));
+  return g;
+}
+
+int finish_group(Group* g) {
+  int32_t depth = 1;
+  LP_TRY(lpamd_chain_depth(g->shards[0].eng, &depth));
+  g->chain = depth;
+  if (const char* env = getenv("LPAMD_SHARD_CHAIN")) g->chain = std::max(1, std::min(depth, atoi(env)));
+  return LPAMD_OK;
+}
+
+#define CHECK_GROUP(g)                                                   \
+  do {                                                                   \
+    if (!(g) || (g)->shards.empty()) return set_err(LPAMD_E_ARG, "null group"); \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int lpamd_comm_unique_id(void* id_out) {
+  if (!id_out) return set_err(LPAMD_E_ARG, "comm_unique_id: null");
+  static_assert(sizeof(ncclUniqueId) == LPAMD_COMM_ID_BYTES, "LPAMD_COMM_ID_BYTES must match ncclUniqueId");
+  RcclApi* api = nullptr;
+  LP_TRY(rccl_api(&api));
+  ncclUniqueId id;
+  RCCL_TRY(api, api->GetUniqueId(&id));
+  std::memcpy(id_out, &id, sizeof(id));
+  return LPAMD_OK;
+}
+
+int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards, const int32_t* devices, int32_t flags) {
+  if (!out) return set_err(LPAMD_E_ARG, "group_create: out is null");
+  *out = nullptr;
+  if (m <= 0 || N <= 0 || n_shards <= 0 || n_shards > N + 1) return set_err(LPAMD_E_ARG, "group_create: bad shape m=%lld N=%lld shards=%d", (long long)m, (long long)N, n_shards);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
+  const bool local = (flags & LPAMD_GROUP_LOCAL_EXCHANGE) != 0;
+  std::vector<int> devs(n_shards);
+  for (int k = 0; k < n_shards; k++) {
+    devs[k] = devices ? devices[k] : k;
+    if (devs[k] < 0 || devs[k] >= ndev) return set_err(LPAMD_E_NODEVICE, "group_create: shard %d wants device %d, %d visible", k, devs[k], ndev);
+    for (int q = 0; q < k && !local; q++)
+      if (devs[q] == devs[k]) return set_err(LPAMD_E_ARG, "group_create: device %d used twice (RCCL needs one GPU per shard)", devs[k]);
+  }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  Group* g = new_group(m, N, n_shards, flags);
+  g->shards.resize(n_shards);
+  int rc = LPAMD_OK;
+  for (int k = 0; k < n_shards && rc == LPAMD_OK; k++) rc = init_shard(g, g->shards[k], k, devs[k]);
+  if (rc == LPAMD_OK && !local) {
+    RcclApi* api = nullptr;
+    rc = rccl_api(&api);
+    if (rc == LPAMD_OK) {
+      std::vector<ncclComm_t> comms(n_shards, nullptr);
+      ncclResult_t r = api->CommInitAll(comms.data(), n_shards, devs.data());
+      if (r != ncclSuccess) rc = set_err(LPAMD_E_HIP, "ncclCommInitAll failed: %s", api->GetErrorString(r));
+      else for (int k = 0; k < n_shards; k++) g->shards[k].comm = comms[k];
+    }
+  }
+  if (rc == LPAMD_OK) rc = finish_group(g);
+  (void)hipSetDevice(prev);
+  if (rc != LPAMD_OK) {
+    char keep[sizeof(g_err)];
+    std::memcpy(keep, g_err, sizeof(keep));
+    lpamd_group_destroy(g);
+    std::memcpy(g_err, keep, sizeof(keep));
+    return rc;
+  }
+  *out = g;
+  return LPAMD_OK;
+}
+
+int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id) {
+  if (!out) return set_err(LPAMD_E_ARG, "group_create_rank: out is null");
+  *out = nullptr;
+  if (m <= 0 || N <= 0 || world <= 0 || rank < 0 || rank >= world || !comm_id)
+    return set_err(LPAMD_E_ARG, "group_create_rank: bad arguments m=%lld N=%lld rank=%d world=%d", (long long)m, (long long)N, rank, world);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
+  Group* g = new_group(m, N, world, 0);
+  g->shards.resize(1);
+  int rc = init_shard(g, g->shards[0], rank, dev);
+  if (rc == LPAMD_OK) {
+    RcclApi* api = nullptr;
+    rc = rccl_api(&api);
+    if (rc == LPAMD_OK) {
+      ncclUniqueId id;
+      std::memcpy(&id, comm_id, sizeof(id));
+      ncclResult_t r = api->CommInitRank(&g->shards[0].comm, world, id, rank);
+      if (r != ncclSuccess) rc = set_err(LPAMD_E_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(r));
+    }
+  }
+  if (rc == LPAMD_OK) rc = finish_group(g);
+  if (rc != LPAMD_OK) {
+    char keep[sizeof(g_err)];
+    std::memcpy(keep, g_err, sizeof(keep));
+    lpamd_group_destroy(g);
+    std::memcpy(g_err, keep, sizeof(keep));
+    return rc;
+  }
+  *out = g;
+  return LPAMD_OK;
+}
+
+int lpamd_group_destroy(lpamd_group* g) {
+  if (!g) return LPAMD_OK;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (Shard& s : g->shards) destroy_shard(g, s);
+  (void)hipSetDevice(prev);
+  delete g;
+  return LPAMD_OK;
+}
+
+int lpamd_group_shards(const lpamd_group* g, int32_t* n_local, int32_t* world) {
+  CHECK_GROUP(g);
+  if (n_local) *n_local = (int32_t)g->shards.size();
+  if (world) *world = g->world;
+  return LPAMD_OK;
+}
+
+int lpamd_group_engine(lpamd_group* g, int32_t local_index, lpamd_engine** out) {
+  CHECK_GROUP(g);
+  if (!out || local_index < 0 || local_index >= (int32_t)g->shards.size()) return set_err(LPAMD_E_ARG, "group_engine: bad index %d", local_index);
+  *out = g->shards[local_index].eng;
+  return LPAMD_OK;
+}
+
+int lpamd_group_chain(lpamd_group* g, int32_t* pivots_per_pass) {
+  CHECK_GROUP(g);
+  if (!pivots_per_pass) return set_err(LPAMD_E_ARG, "group_chain: null");
+  *pivots_per_pass = g->chain;
+  return LPAMD_OK;
+}
+
+int lpamd_group_upload(lpamd_group* g, const double* T, int64_t ld, const double* obj, const uint8_t* is_basic) {
+  CHECK_GROUP(g);
+  return for_each_shard(g, [&](Shard& s) { return lpamd_upload(s.eng, T, ld, obj, is_basic); });
+}
+
+int lpamd_group_fill_synthetic(lpamd_group* g, int64_t n_struct, uint64_t seed) {
+  CHECK_GROUP(g);
+  return for_each_shard(g, [&](Shard& s) { return lpamd_fill_synthetic(s.eng, n_struct, seed); });
+}
+
+int lpamd_group_download(lpamd_group* g, double* T, int64_t ld, double* obj, uint8_t* is_basic) {
+  CHECK_GROUP(g);
+  for (Shard& s : g->shards) {   // one after the other: the shards write disjoint columns of the same host matrix
+    HIP_TRY(hipSetDevice(s.device));
+    LP_TRY(lpamd_download(s.eng, T, ld, obj, is_basic));
+  }
+  return LPAMD_OK;
+}
+
+int lpamd_group_run_pivots(lpamd_group* g, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
+  CHECK_GROUP(g);
+  if (!result) return set_err(LPAMD_E_ARG, "group_run_pivots: null result");
+  std::vector<int32_t> res(g->shards.size(), LPAMD_ERROR);
+  std::vector<int64_t> dn(g->shards.size(), 0);
+  LP_TRY(for_each_shard(g, [&](Shard& s) {
+    const size_t k_local = &s - g->shards.data();
+    return run_pivots_shard(g, s, strategy, k, &res[k_local], &dn[k_local]);
+  }));
+  for (size_t q = 1; q < res.size(); q++)
+    if (res[q] != res[0] || dn[q] != dn[0]) return set_err(LPAMD_E_STATE, "shards disagree: result %d/%d, pivots %lld/%lld", res[0], res[q], (long long)dn[0], (long long)dn[q]);
+  *result = res[0];
+  if (done) *done = dn[0];
+  return LPAMD_OK;
+}
+
+int lpamd_group_solve(lpamd_group* g, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots) {
+  CHECK_GROUP(g);
+  if (!result) return set_err(LPAMD_E_ARG, "group_solve: null result");
+  if (strategy != LPAMD_MAX_COST && strategy != LPAMD_MAX_REDUCTION)
+    return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+  std::vector<int32_t> res(g->shards.size(), LPAMD_ERROR);
+  std::vector<int64_t> np(g->shards.size(), 0);
+  LP_TRY(for_each_shard(g, [&](Shard& s) {
+    const size_t k_local = &s - g->shards.data();
+    return solve_shard(g, s, strategy, max_pivots, &res[k_local], &np[k_local]);
+  }));
+  for (size_t q = 1; q < res.size(); q++)
+    if (res[q] != res[0] || np[q] != np[0]) return set_err(LPAMD_E_STATE, "shards disagree: result %d/%d, pivots %lld/%lld", res[0], res[q], (long long)np[0], (long long)np[q]);
+  *result = res[0];
+  if (n_pivots) *n_pivots = np[0];
+  return LPAMD_OK;
+}
+
+int lpamd_group_pivot(lpamd_group* g, int64_t d, int64_t e, int64_t r) {
+  CHECK_GROUP(g);
+  if (e < 0 || e > g->N + 1 || e == g->N || r < 0 || r >= g->m || d > g->N + 1) return set_err(LPAMD_E_ARG, "group_pivot: bad arguments d=%lld e=%lld r=%lld", (long long)d, (long long)e, (long long)r);
+  return for_each_shard(g, [&](Shard& s) {
+    std::vector<double> obj(g->N + 2, 0.0);
+    LP_TRY(assembled_objective(g, s, obj));
+    return pivot_shards(g, s, d, e, r, obj[e]);
+  });
+}
+
+int lpamd_group_need_init(lpamd_group* g, int32_t* out) {
+  CHECK_GROUP(g);
+  HIP_TRY(hipSetDevice(g->shards[0].device));
+  return lpamd_need_init(g->shards[0].eng, out);   // the right-hand side is replicated
+}
+
+int lpamd_group_phase1(lpamd_group* g, int32_t strategy, int32_t* result) {
+  CHECK_GROUP(g);
+  if (!result) return set_err(LPAMD_E_ARG, "group_phase1: null result");
+  std::vector<int32_t> res(g->shards.size(), LPAMD_ERROR);
+  LP_TRY(for_each_shard(g, [&](Shard& s) { return phase1_shard(g, s, strategy, &res[&s - g->shards.data()]); }));
+  *result = res[0];
+  return LPAMD_OK;
+}
+
+int lpamd_group_column_values(lpamd_group* g, double* x) {
+  CHECK_GROUP(g);
+  if (!x) return set_err(LPAMD_E_ARG, "group_column_values: null");
+  return for_each_shard(g, [&](Shard& s) {
+    std::vector<double> v(g->N + 2, 0.0);
+    LP_TRY(lpamd_column_values(s.eng, v.data()));
+    LP_TRY(assemble(g, s, v));
+    if (&s == g->shards.data()) std::memcpy(x, v.data(), sizeof(double) * (g->N + 2));
+    return (int)LPAMD_OK;
+  });
+}
+
+int lpamd_group_objective_constant(lpamd_group* g, double* out) {
+  CHECK_GROUP(g);
+  HIP_TRY(hipSetDevice(g->shards[0].device));
+  return lpamd_objective_constant(g->shards[0].eng, out);   // replicated with the right-hand side
+}
+
+int lpamd_group_pivot_count(lpamd_group* g, int64_t* n) {
+  CHECK_GROUP(g);
+  HIP_TRY(hipSetDevice(g->shards[0].device));
+  return lpamd_pivot_count(g->shards[0].eng, n);
+}
+
+int lpamd_group_trace(lpamd_group* g, int64_t* e, int64_t* r, int64_t cap, int64_t* n) {
+  CHECK_GROUP(g);
+  HIP_TRY(hipSetDevice(g->shards[0].device));
+  return lpamd_trace(g->shards[0].eng, e, r, cap, n);       // every rank records the full trace
+}
+
+}  // extern "C"

@@ -69,6 +69,8 @@ def library():
         "lpamd_set_profiling": (ctypes.c_int, [vp, i32]),
         "lpamd_update_stats": (ctypes.c_int, [vp, P(ctypes.c_double), P(i64), P(i64)]),
         "lpamd_pass_stats": (ctypes.c_int, [vp, P(ctypes.c_int32), P(i64), P(i64)]),
+        "lpamd_profile_totals": (ctypes.c_int, [vp, P(ctypes.c_double), P(i64), P(i64), P(i64), P(i64)]),
+        "lpamd_loop_depth": (ctypes.c_int, [vp, i32, P(i32)]),
         "lpamd_local_candidate": (ctypes.c_int, [vp, i32, vp]),
         "lpamd_select_candidate": (ctypes.c_int, [vp, i32, vp, i32, P(i64), P(i64), P(i32), P(i32)]),
         "lpamd_fold_candidates": (ctypes.c_int, [i32, vp, i32, i64, P(i64), P(i64), P(i32), P(i32), vp]),
@@ -87,6 +89,25 @@ def library():
         "lpamd_fill_column": (ctypes.c_int, [vp, i64, ctypes.c_double]),
         "lpamd_set_basic_flag": (ctypes.c_int, [vp, i64, i32]),
         "lpamd_pivot_shard": (ctypes.c_int, [vp, i64, i64, i64, ctypes.c_double, vp]),
+        "lpamd_comm_unique_id": (ctypes.c_int, [vp]),
+        "lpamd_group_create": (ctypes.c_int, [P(vp), i64, i64, i32, vp, i32]),
+        "lpamd_group_create_rank": (ctypes.c_int, [P(vp), i64, i64, i32, i32, vp]),
+        "lpamd_group_destroy": (ctypes.c_int, [vp]),
+        "lpamd_group_shards": (ctypes.c_int, [vp, P(i32), P(i32)]),
+        "lpamd_group_engine": (ctypes.c_int, [vp, i32, P(vp)]),
+        "lpamd_group_chain": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_group_upload": (ctypes.c_int, [vp, vp, i64, vp, vp]),
+        "lpamd_group_fill_synthetic": (ctypes.c_int, [vp, i64, u64]),
+        "lpamd_group_download": (ctypes.c_int, [vp, vp, i64, vp, vp]),
+        "lpamd_group_need_init": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_group_phase1": (ctypes.c_int, [vp, i32, P(i32)]),
+        "lpamd_group_solve": (ctypes.c_int, [vp, i32, i64, P(i32), P(i64)]),
+        "lpamd_group_run_pivots": (ctypes.c_int, [vp, i32, i64, P(i32), P(i64)]),
+        "lpamd_group_pivot": (ctypes.c_int, [vp, i64, i64, i64]),
+        "lpamd_group_column_values": (ctypes.c_int, [vp, vp]),
+        "lpamd_group_objective_constant": (ctypes.c_int, [vp, P(ctypes.c_double)]),
+        "lpamd_group_pivot_count": (ctypes.c_int, [vp, P(i64)]),
+        "lpamd_group_trace": (ctypes.c_int, [vp, vp, vp, i64, P(i64)]),
         "lpamd_rev_create": (ctypes.c_int, [P(vp), i64, i64, vp]),
         "lpamd_rev_destroy": (ctypes.c_int, [vp]),
         "lpamd_rev_upload": (ctypes.c_int, [vp, vp, i64, vp, vp, i32]),
@@ -127,17 +148,21 @@ def fold_candidates(strategy, records, world, N):
 class TableauEngine:
     """Device-resident m x (N+2) tableau shard on the current HIP device."""
 
-    def __init__(self, m, N, rank=0, world=1, stream=None):
+    def __init__(self, m, N, rank=0, world=1, stream=None, borrowed=None):
         self.L = library()
         self.m, self.N, self.rank, self.world = int(m), int(N), int(rank), int(world)
+        self.owned = borrowed is None
+        if borrowed is not None:          # a shard of a ShardGroup: the group owns the handle
+            self.h = ctypes.c_void_p(borrowed)
+            return
         self.h = ctypes.c_void_p()
         _ck(self.L.lpamd_create(ctypes.byref(self.h), self.m, self.N, self.rank, self.world,
                                 ctypes.c_void_p(stream) if stream else None))
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             self.L.lpamd_destroy(self.h)
-            self.h = ctypes.c_void_p()
+        self.h = ctypes.c_void_p()
 
     def __del__(self):
         try:
@@ -163,6 +188,18 @@ class TableauEngine:
         is_basic = np.zeros(self.N + 2, dtype=np.uint8)
         _ck(self.L.lpamd_download(self.h, T.ctypes.data, self.m, obj.ctypes.data, is_basic.ctypes.data))
         return T, obj, is_basic
+
+    def download_objective(self):
+        """Objective row only (entries of columns other ranks own stay 0); the tableau is not copied."""
+        obj = np.zeros(self.N + 2, dtype=np.float64)
+        _ck(self.L.lpamd_download(self.h, None, 0, obj.ctypes.data, None))
+        return obj
+
+    def download_basic(self):
+        """Basis flags only (tableau_is_base_variable_, reference lp.cc:156-166)."""
+        is_basic = np.zeros(self.N + 2, dtype=np.uint8)
+        _ck(self.L.lpamd_download(self.h, None, 0, None, is_basic.ctypes.data))
+        return is_basic
 
     def read_column(self, j):
         out = np.zeros(self.m, dtype=np.float64)
@@ -260,6 +297,17 @@ class TableauEngine:
         _ck(self.L.lpamd_pass_stats(self.h, ctypes.byref(k), ctypes.byref(s), ctypes.byref(t)))
         return k.value, s.value, t.value
 
+    def profile_totals(self):
+        """Since set_profiling(True): (ms inside the update kernel, passes, pivots, columns streamed, columns touched)."""
+        ms, a, b, c, d = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_profile_totals(self.h, ctypes.byref(ms), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+        return ms.value, a.value, b.value, c.value, d.value
+
+    def loop_depth(self, strategy):
+        d = ctypes.c_int32()
+        _ck(self.L.lpamd_loop_depth(self.h, int(strategy), ctypes.byref(d)))
+        return d.value
+
     # ---- multi-GPU steps (device pointers are plain ints, e.g. tensor.data_ptr()) ----
     def local_candidate(self, strategy, cand_ptr):
         _ck(self.L.lpamd_local_candidate(self.h, int(strategy), ctypes.c_void_p(cand_ptr)))
@@ -331,6 +379,127 @@ class TableauEngine:
 
     def pivot_shard(self, d, e, r, ce, xbuf_ptr):
         _ck(self.L.lpamd_pivot_shard(self.h, int(d), int(e), int(r), float(ce), ctypes.c_void_p(xbuf_ptr) if xbuf_ptr else None))
+
+
+def comm_unique_id():
+    """128-byte RCCL id for ShardGroup.join; made on one rank, delivered to the others by the caller."""
+    buf = ctypes.create_string_buffer(128)
+    _ck(library().lpamd_comm_unique_id(buf))
+    return buf.raw
+
+
+class ShardGroup:
+    """One LP over column shards, driven by the library (lpamd_group_*): RCCL collectives and the
+    pivot loop live behind the C ABI.  ShardGroup(m, N, n_shards, devices) runs all shards from this
+    process (local_exchange=True: device copies instead of RCCL, shards may share a GPU);
+    ShardGroup.join(m, N, rank, world, comm_id) is the one-process-per-GPU form."""
+
+    def __init__(self, m, N, n_shards=1, devices=None, local_exchange=False, _joined=None):
+        self.L = library()
+        self.m, self.N = int(m), int(N)
+        self.h = ctypes.c_void_p()
+        if _joined is not None:
+            rank, world, comm_id = _joined
+            _ck(self.L.lpamd_group_create_rank(ctypes.byref(self.h), self.m, self.N, int(rank), int(world), comm_id))
+        else:
+            dev = None
+            if devices is not None:
+                dev = (ctypes.c_int32 * int(n_shards))(*[int(d) for d in devices])
+            _ck(self.L.lpamd_group_create(ctypes.byref(self.h), self.m, self.N, int(n_shards), dev, 1 if local_exchange else 0))
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        _ck(self.L.lpamd_group_shards(self.h, ctypes.byref(a), ctypes.byref(b)))
+        self.n_local, self.world = a.value, b.value
+
+    @classmethod
+    def join(cls, m, N, rank, world, comm_id):
+        return cls(m, N, _joined=(rank, world, comm_id))
+
+    def close(self):
+        if self.h:
+            self.L.lpamd_group_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def engine(self, k=0):
+        """Local shard k as a TableauEngine view (trace, statistics, read-back; the group keeps ownership)."""
+        h = ctypes.c_void_p()
+        _ck(self.L.lpamd_group_engine(self.h, int(k), ctypes.byref(h)))
+        e = TableauEngine(self.m, self.N, borrowed=h.value)
+        e.world = self.world
+        return e
+
+    def chain(self):
+        d = ctypes.c_int32()
+        _ck(self.L.lpamd_group_chain(self.h, ctypes.byref(d)))
+        return d.value
+
+    def upload(self, T, obj, is_basic):
+        T = np.asfortranarray(T, dtype=np.float64)
+        assert T.shape == (self.m, self.N + 2), (T.shape, self.m, self.N)
+        obj = np.ascontiguousarray(obj, dtype=np.float64)
+        is_basic = np.ascontiguousarray(is_basic, dtype=np.uint8)
+        _ck(self.L.lpamd_group_upload(self.h, T.ctypes.data, max(T.strides[1] // 8, self.m), obj.ctypes.data, is_basic.ctypes.data))
+
+    def fill_synthetic(self, n_struct, seed):
+        _ck(self.L.lpamd_group_fill_synthetic(self.h, int(n_struct), int(seed)))
+
+    def download(self, tableau=True):
+        T = np.zeros((self.m, self.N + 2), dtype=np.float64, order="F") if tableau else None
+        obj = np.zeros(self.N + 2, dtype=np.float64)
+        is_basic = np.zeros(self.N + 2, dtype=np.uint8)
+        _ck(self.L.lpamd_group_download(self.h, T.ctypes.data if tableau else None, self.m, obj.ctypes.data, is_basic.ctypes.data))
+        return T, obj, is_basic
+
+    def need_init(self):
+        v = ctypes.c_int32()
+        _ck(self.L.lpamd_group_need_init(self.h, ctypes.byref(v)))
+        return bool(v.value)
+
+    def phase1(self, strategy):
+        res = ctypes.c_int32()
+        _ck(self.L.lpamd_group_phase1(self.h, int(strategy), ctypes.byref(res)))
+        return res.value
+
+    def solve(self, strategy, max_pivots=-1):
+        res, n = ctypes.c_int32(), ctypes.c_int64()
+        _ck(self.L.lpamd_group_solve(self.h, int(strategy), int(max_pivots), ctypes.byref(res), ctypes.byref(n)))
+        return res.value, n.value
+
+    def run_pivots(self, strategy, k):
+        res, n = ctypes.c_int32(), ctypes.c_int64()
+        _ck(self.L.lpamd_group_run_pivots(self.h, int(strategy), int(k), ctypes.byref(res), ctypes.byref(n)))
+        return res.value, n.value
+
+    def pivot(self, d, e, r):
+        _ck(self.L.lpamd_group_pivot(self.h, int(d), int(e), int(r)))
+
+    def column_values(self):
+        x = np.zeros(self.N + 2, dtype=np.float64)
+        _ck(self.L.lpamd_group_column_values(self.h, x.ctypes.data))
+        return x
+
+    def objective_constant(self):
+        v = ctypes.c_double()
+        _ck(self.L.lpamd_group_objective_constant(self.h, ctypes.byref(v)))
+        return v.value
+
+    def pivot_count(self):
+        n = ctypes.c_int64()
+        _ck(self.L.lpamd_group_pivot_count(self.h, ctypes.byref(n)))
+        return n.value
+
+    def trace(self):
+        n = self.pivot_count()
+        e = np.zeros(max(n, 1), dtype=np.int64)
+        r = np.zeros(max(n, 1), dtype=np.int64)
+        got = ctypes.c_int64()
+        _ck(self.L.lpamd_group_trace(self.h, e.ctypes.data, r.ctypes.data, n, ctypes.byref(got)))
+        return list(zip(e[:n].tolist(), r[:n].tolist()))
 
 
 class RevisedTableauEngine:

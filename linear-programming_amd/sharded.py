@@ -1,4 +1,9 @@
-"""Column-sharded pivot loop over several GPUs, one process per GPU.
+"""Column-sharded pivot loop driven from Python over the step-wise C ABI, one process per GPU.
+
+The library runs the same loops itself behind lpamd_group_* (RCCL inside, no Python in the loop;
+that is what bench.py and the `solver` binary use).  This module is the caller-driven form: it shows
+how a host that owns the collectives drives the engines step by step, and it is the harness of
+the multi-process CPU tests, where a host stand-in takes the place of the GPU shard.
 
 Each rank owns the tableau columns whose ordinal is congruent to its rank
 (round-robin deal, so the dense columns stay balanced while the basis drifts)
@@ -134,10 +139,10 @@ class EngineShard:
         return self.eng.read_column(col)
 
     def download_objective(self):
-        return self.eng.download()[1]
+        return self.eng.download_objective()
 
     def download_basic(self):
-        return self.eng.download()[2]
+        return self.eng.download_basic()
 
     def write_objective(self, obj):
         self.eng.write_objective(obj)
@@ -192,10 +197,14 @@ class ShardedSolver:
     status every `poll_every` pivots.
     exchange="broadcast": the host reads the gathered candidates each pivot to learn
     the owner and broadcasts the column from it.
+    exchange="fused": ONE all-gather per pivot, the protocol of the library's own loop
+    (lpamd_group_*): every rank sends its candidate record together with the candidate column
+    itself in one slot; every rank folds the records and takes the winner's column from the
+    winner's slot.  MAX_COST runs it as the look-ahead loop with chains of pivots per pass.
     """
 
     def __init__(self, shard, group=None, exchange="lookahead", poll_every=64, comm=None, chain=None):
-        assert exchange in ("lookahead", "allreduce", "broadcast")
+        assert exchange in ("lookahead", "allreduce", "broadcast", "fused")
         self.shard = shard
         # look-ahead loop: pivots set up per pass over the shard (1: one pivot per pass); shards without
         # lpamd_chain_step (the host stand-in of the CPU tests) keep one pivot per pass
@@ -217,6 +226,9 @@ class ShardedSolver:
         self.xbuf = shard.new_buffer(shard.exchange_doubles())
         self.xbuf_words = self.xbuf.view(torch.int64)
         self.xlocal = shard.new_buffer(shard.exchange_doubles())    # look-ahead: this rank's next candidate column
+        self.slot_words = 8 + shard.exchange_doubles()              # fused exchange: 64-byte header (record) + column
+        self.slot = shard.new_buffer(self.slot_words) if exchange == "fused" else None
+        self.slots = shard.new_buffer(self.slot_words * self.world) if exchange == "fused" else None
         self.ev_sent = self.ev_arrived = None
         if self.xbuf.is_cuda and getattr(shard, "xstream", None) is not None:
             self.ev_sent, self.ev_arrived = torch.cuda.Event(), torch.cuda.Event()
@@ -229,7 +241,9 @@ class ShardedSolver:
         """At most k pivots (k < 0: until termination).  Returns (Result, pivots done)."""
         if self.exchange == "broadcast":
             run = self._run_broadcast
-        elif self.exchange == "lookahead" and strategy == _eng.MAX_COST:
+        elif self.exchange == "fused" and strategy != _eng.MAX_COST:
+            run = self._run_fused_in_order
+        elif self.exchange in ("lookahead", "fused") and strategy == _eng.MAX_COST:
             run = self._run_lookahead
         else:
             run = self._run_allreduce
@@ -276,12 +290,57 @@ class ShardedSolver:
         if two_streams:
             self.ev_sent.record(sh.stream)
             sh.xstream.wait_event(self.ev_sent)
-        self._gather_candidates()
-        sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
-        if self.use_dist:
-            self.comm.all_reduce_sum_words(self.xbuf_words)
+        if self.exchange == "fused":
+            owner = self._slot_exchange(_eng.MAX_COST)
+            sh.lookahead_select(self.cands, self.xlocal, self.xbuf)      # keeps the winner's record in the engine
+            if owner >= 0:
+                self.xbuf.copy_(self.slots.view(self.world, self.slot_words)[owner, 8:])
+        else:
+            self._gather_candidates()
+            sh.lookahead_select(self.cands, self.xlocal, self.xbuf)
+            if self.use_dist:
+                self.comm.all_reduce_sum_words(self.xbuf_words)
         if two_streams:
             self.ev_arrived.record(sh.xstream)
+
+    def _slot_exchange(self, strategy):
+        """The fused exchange: record (self.cand) and column (self.xlocal) travel in one all-gather.
+        Leaves the records in self.cands; returns the winner's rank (-1: no winner).  The harness
+        folds on the host; the library's loop does the same fold in a kernel."""
+        self.slot[:4].copy_(self.cand)
+        self.slot[8:].copy_(self.xlocal)
+        if self.use_dist:
+            self.comm.all_gather(self.slots, self.slot)
+        else:
+            self.slots.copy_(self.slot)
+        self.cands.copy_(self.slots.view(self.world, self.slot_words)[:, :4].reshape(-1))
+        _, _, owner, _, _ = _eng.fold_candidates(strategy, self.cands.cpu().numpy(), self.world, self.shard.N)
+        return owner
+
+    def _run_fused_in_order(self, strategy, k):
+        """Pricing on the current tableau, ONE all-gather of record + column, fold, pivot."""
+        sh = self.shard
+        start = sh.pivot_count()
+        sh.set_pivot_budget(k)
+        enqueued = 0
+        while True:
+            n = self.poll_every if k < 0 else min(self.poll_every, k - enqueued)
+            for _ in range(n):
+                sh.local_candidate(strategy, self.cand)
+                gcol = int(self.cand.cpu().view(torch.int64)[1])
+                self.xlocal.zero_()
+                if gcol >= 0:
+                    sh.export_column(gcol, self.xlocal)
+                owner = self._slot_exchange(strategy)
+                sh.select_candidate_device(strategy, self.cands)      # winner + status (budget, optimum, unbounded)
+                if owner >= 0:
+                    self.xbuf.copy_(self.slots.view(self.world, self.slot_words)[owner, 8:])
+                sh.apply_pivot(strategy, -1, -1, self.xbuf)
+            enqueued += n
+            res = sh.poll()
+            if res != _eng.LIMIT or (k >= 0 and enqueued >= k):
+                break
+        return res, sh.pivot_count() - start
 
     def _run_lookahead(self, strategy, k):
         assert strategy == _eng.MAX_COST

@@ -62,6 +62,16 @@ def lib():
         L.lpo_synth_entry.argtypes = [ctypes.c_uint64, i64, i64, i64, i64]
         L.lpo_synth_entry.restype = ctypes.c_double
         L.lpo_num_threads.restype = ctypes.c_int
+        vp = ctypes.c_void_p
+        L.lpo_stream_create.argtypes = [ctypes.c_uint64, i64, i64, i64]
+        L.lpo_stream_create.restype = vp
+        L.lpo_stream_free.argtypes = [vp]
+        L.lpo_stream_free.restype = None
+        L.lpo_stream_run.argtypes = [vp, ctypes.c_int, i64]
+        L.lpo_stream_column.argtypes = [vp, i64, vp]
+        L.lpo_stream_column.restype = None
+        L.lpo_stream_state.argtypes = [vp, vp, vp, vp, vp, vp]
+        L.lpo_stream_state.restype = i64
         _lib = L
     return _lib
 
@@ -142,6 +152,40 @@ class DenseTableau:
         x = np.zeros(self.ncols, dtype=np.float64)
         lib().lpo_column_values(ctypes.byref(self.s), x.ctypes.data)
         return x
+
+
+class StreamedSynthetic:
+    """The synthetic LP without a tableau in memory: every entry is regenerated from (seed, i, j) and
+    the pivots so far (see lp_oracle_core.c); for the benchmark sizes the host cannot store."""
+
+    def __init__(self, m, n, seed, kmax=64):
+        self.m, self.n, self.N, self.ncols, self.kmax = m, n, n + m, n + m + 2, kmax
+        self.h = lib().lpo_stream_create(seed, m, n, kmax)
+        if not self.h:
+            raise MemoryError("lpo_stream_create")
+
+    def run(self, strategy, budget):
+        return lib().lpo_stream_run(self.h, strategy, budget)
+
+    def column(self, j):
+        out = np.zeros(self.m, dtype=np.float64)
+        lib().lpo_stream_column(self.h, int(j), out.ctypes.data)
+        return out
+
+    def state(self):
+        """(trace, objective row, right-hand side, basis flags)"""
+        te, tr = np.zeros(self.kmax, dtype=np.int64), np.zeros(self.kmax, dtype=np.int64)
+        obj, rhs, basic = np.zeros(self.ncols), np.zeros(self.m), np.zeros(self.ncols, dtype=np.uint8)
+        k = lib().lpo_stream_state(self.h, te.ctypes.data, tr.ctypes.data, obj.ctypes.data, rhs.ctypes.data, basic.ctypes.data)
+        return list(zip(te[:k].tolist(), tr[:k].tolist())), obj, rhs, basic
+
+    def close(self):
+        if self.h:
+            lib().lpo_stream_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 def from_text(text, **kw):

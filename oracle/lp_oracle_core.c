@@ -602,3 +602,187 @@ int lpo_revised_solve(lpo_rev_t *p) {
   for (int64_t i = 0; i < m; i++) p->cB[i] = p->obj[p->basis[i]];  /* :194-195 */
   return rev_main_loop(p, W0);
 }
+
+/* ======================================================================
+ * Storage-free restatement for the SYNTHETIC LP (test infrastructure).
+ * The two largest benchmark configurations do not fit the host (m=65536
+ * n=262144 stores 172 GB), so the dense restatement above cannot check them.
+ * Every entry of the synthetic tableau is a pure function of (seed, i, j), and
+ * a pivot changes entry (i, j) by the rank-1 formula of reference
+ * lp_simplex_tableau.cc:45-46 only, so the entry after s pivots is
+ *   flushz(... flushz(flushz(T0_ij + col'_0[i]*row'_0[j]) + col'_1[i]*row'_1[j]) ...)
+ * with the col'/row' vectors of the pivots so far (m and ncols doubles each).
+ * The functions below run the main loop of reference
+ * lp_simplex_tableau.cc:181-377 on entries regenerated this way: same
+ * operations in the same order as lpo_pivot / lpo_price_* / lpo_ratio_test
+ * (a step whose row' entry for the column is exactly 0 is skipped, which is
+ * what skip_zero_cols does and changes no bit), no tableau in memory.
+ * tests/test_oracle_goldens.py checks it against the dense restatement.
+ * ====================================================================== */
+typedef struct {
+  uint64_t seed;
+  int64_t m, n, N, ncols, kmax, k;   /* k = pivots applied so far */
+  double *colp;                       /* kmax * m */
+  double *rowp;                       /* kmax * ncols */
+  double *obj, *rhs;                  /* ncols, m: current objective row and right-hand side */
+  uint8_t *is_basic;                  /* ncols */
+  int64_t *basis;                     /* m */
+  int64_t *trace_e, *trace_r;         /* kmax */
+} lpo_stream_t;
+
+void lpo_stream_free(lpo_stream_t *h) {
+  if (!h) return;
+  free(h->colp); free(h->rowp); free(h->obj); free(h->rhs); free(h->is_basic); free(h->basis);
+  free(h->trace_e); free(h->trace_r); free(h);
+}
+
+lpo_stream_t *lpo_stream_create(uint64_t seed, int64_t m, int64_t n, int64_t kmax) {
+  lpo_stream_t *h = (lpo_stream_t *)calloc(1, sizeof(lpo_stream_t));
+  if (!h) return NULL;
+  h->seed = seed; h->m = m; h->n = n; h->N = n + m; h->ncols = n + m + 2; h->kmax = kmax; h->k = 0;
+  h->colp = (double *)malloc(sizeof(double) * (size_t)(kmax * m));
+  h->rowp = (double *)malloc(sizeof(double) * (size_t)(kmax * h->ncols));
+  h->obj = (double *)malloc(sizeof(double) * (size_t)h->ncols);
+  h->rhs = (double *)malloc(sizeof(double) * (size_t)m);
+  h->is_basic = (uint8_t *)malloc((size_t)h->ncols);
+  h->basis = (int64_t *)malloc(sizeof(int64_t) * (size_t)m);
+  h->trace_e = (int64_t *)malloc(sizeof(int64_t) * (size_t)kmax);
+  h->trace_r = (int64_t *)malloc(sizeof(int64_t) * (size_t)kmax);
+  if (!h->colp || !h->rowp || !h->obj || !h->rhs || !h->is_basic || !h->basis || !h->trace_e || !h->trace_r) {
+    lpo_stream_free(h);
+    return NULL;
+  }
+  for (int64_t j = 0; j < h->ncols; j++) {
+    h->obj[j] = lpo_synth_entry(seed, m, n, m, j);
+    h->is_basic[j] = (j >= n && j < n + m) ? 1 : 0;
+  }
+  for (int64_t i = 0; i < m; i++) {
+    h->rhs[i] = lpo_synth_entry(seed, m, n, i, h->N);
+    h->basis[i] = n + i;
+  }
+  return h;
+}
+
+/* column j as the pivots so far leave it */
+void lpo_stream_column(const lpo_stream_t *h, int64_t j, double *out) {
+  const int64_t m = h->m;
+  for (int64_t i = 0; i < m; i++) out[i] = lpo_synth_entry(h->seed, m, h->n, i, j);
+  for (int64_t s = 0; s < h->k; s++) {
+    const double rj = h->rowp[s * h->ncols + j];
+    if (rj == 0.0) continue;
+    const double *c = h->colp + s * m;
+    for (int64_t i = 0; i < m; i++) out[i] = flushz(out[i] + c[i] * rj);   /* lp_simplex_tableau.cc:45-46 */
+  }
+}
+
+static double stream_entry(const lpo_stream_t *h, int64_t i, int64_t j) {
+  double v = lpo_synth_entry(h->seed, h->m, h->n, i, j);
+  for (int64_t s = 0; s < h->k; s++) {
+    const double rj = h->rowp[s * h->ncols + j];
+    if (rj != 0.0) v = flushz(v + h->colp[s * h->m + i] * rj);
+  }
+  return v;
+}
+
+/* At most `budget` further pivots (never beyond kmax in total). Returns LPO_LIMIT when the budget
+ * or kmax ends the run, otherwise the terminal Result. */
+int lpo_stream_run(lpo_stream_t *h, int strategy, int64_t budget) {
+  const int64_t m = h->m, nc = h->ncols, N = h->N;
+  double *col = (double *)malloc(sizeof(double) * (size_t)m);
+  double *cmin = (double *)malloc(sizeof(double) * (size_t)nc);
+  int64_t *crow = (int64_t *)malloc(sizeof(int64_t) * (size_t)nc);
+  int rc = LPO_LIMIT;
+  for (int64_t done = 0; done < budget && h->k < h->kmax; done++) {
+    int64_t e = -1, r = -1;
+    if (strategy == LPO_MAX_COST) {
+      double best = -DBL_MAX;                               /* :188-198 */
+      for (int64_t j = 0; j < nc; j++) {
+        if (j == N || h->is_basic[j]) continue;
+        const double c = h->obj[j];
+        if (is_pos(c) && c > best) { best = c; e = j; }
+      }
+      if (e < 0) { rc = LPO_SOLVED; break; }
+      lpo_stream_column(h, e, col);
+      double bestr = DBL_MAX;                               /* :207-227 */
+      for (int64_t i = 0; i < m; i++) {
+        const double a = col[i];
+        if (is_zero(a) || is_nonneg(a)) continue;
+        const double ratio = h->rhs[i] / (-a);
+        if (bestr > ratio && h->basis[i] >= 0) { bestr = ratio; r = i; }
+      }
+      if (r < 0) { rc = LPO_UNBOUNDED; break; }
+    } else if (strategy == LPO_MAX_REDUCTION) {
+#pragma omp parallel
+      {
+        double *w = (double *)malloc(sizeof(double) * (size_t)m);
+#pragma omp for schedule(dynamic, 4)
+        for (int64_t j = 0; j < nc; j++) {                  /* :275-309 / :333-352 */
+          crow[j] = -2;
+          if (j == N || h->is_basic[j] || !is_pos(h->obj[j])) continue;
+          lpo_stream_column(h, j, w);
+          double mn = DBL_MAX;
+          int64_t ri = -1;
+          for (int64_t i = 0; i < m; i++) {
+            const double a = w[i];
+            if (is_nonneg(a)) continue;
+            const double ratio = h->rhs[i] / (-a);
+            if (mn > ratio) { mn = ratio; ri = i; }
+          }
+          cmin[j] = mn;
+          crow[j] = ri;
+        }
+        free(w);
+      }
+      double best = -DBL_MAX;                               /* :310-325 / :353-362 */
+      for (int64_t j = 0; j < nc; j++) {
+        if (crow[j] == -2) continue;
+        if (e < 0) e = j;
+        if (crow[j] < 0 || h->basis[crow[j]] < 0) continue;
+        const double score = h->obj[j] * cmin[j];
+        if (score > best) { best = score; e = j; r = crow[j]; }
+      }
+      if (e < 0) { rc = LPO_SOLVED; break; }
+      if (r < 0) { rc = LPO_UNBOUNDED; break; }
+      lpo_stream_column(h, e, col);
+    } else {
+      rc = LPO_ERROR;
+      break;
+    }
+    /* TableauPivot, reference lp_simplex_tableau.cc:10-52, on regenerated entries */
+    const int64_t s = h->k, d = h->basis[r];
+    const double a = col[r];
+    const double ce = h->obj[e];
+    const double g = ce * (-1.0 / a);
+    const double f = -1.0 / a;
+    double *rowp = h->rowp + s * nc, *colp = h->colp + s * m;
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < nc; j++) {
+      const double t = j == N ? h->rhs[r] : stream_entry(h, r, j);
+      h->obj[j] = flushz(h->obj[j] + t * g);
+      rowp[j] = t * f;
+    }
+    h->obj[e] = 0.0;
+    for (int64_t i = 0; i < m; i++) colp[i] = col[i];
+    colp[r] = 1.0 + a;
+    const double rn = rowp[N];
+    if (rn != 0.0)
+      for (int64_t i = 0; i < m; i++) h->rhs[i] = flushz(h->rhs[i] + colp[i] * rn);
+    if (d >= 0 && d < nc) h->is_basic[d] = 0;
+    h->is_basic[e] = 1;
+    h->basis[r] = e;
+    h->trace_e[s] = e;
+    h->trace_r[s] = r;
+    h->k = s + 1;
+  }
+  free(col); free(cmin); free(crow);
+  return rc;
+}
+
+int64_t lpo_stream_state(const lpo_stream_t *h, int64_t *trace_e, int64_t *trace_r, double *obj, double *rhs, uint8_t *is_basic) {
+  if (trace_e) memcpy(trace_e, h->trace_e, sizeof(int64_t) * (size_t)h->k);
+  if (trace_r) memcpy(trace_r, h->trace_r, sizeof(int64_t) * (size_t)h->k);
+  if (obj) memcpy(obj, h->obj, sizeof(double) * (size_t)h->ncols);
+  if (rhs) memcpy(rhs, h->rhs, sizeof(double) * (size_t)h->m);
+  if (is_basic) memcpy(is_basic, h->is_basic, (size_t)h->ncols);
+  return h->k;
+}

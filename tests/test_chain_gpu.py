@@ -57,10 +57,13 @@ def test_budgets_and_continuation(lpamd, depth):
     eng = lpamd.TableauEngine(m, n + m)
     eng.fill_synthetic(n, 7)
     total = 0
-    for k in (1, 2, 37, 1, 1, 4, 3, 8, 9, 16, 17):
+    assert eng.run_pivots(lpamd.MAX_COST, 0) == (lpamd.LIMIT, 0)      # an empty budget is spent, not an error
+    for k in (1, 2, 37, 0, 1, 1, 4, 3, 8, 9, 16, 17):
         res, done = eng.run_pivots(lpamd.MAX_COST, k)
         total += k
         assert (res, done) == (lpamd.LIMIT, k)
+        if k == 0:
+            continue
         assert dt.solve(lo.MAX_COST, max_pivots=total) == lo.LIMIT
         assert eng.pivot_count() == total
         assert eng.trace() == dt.trace()
@@ -73,6 +76,21 @@ def test_budgets_and_continuation(lpamd, depth):
     assert_same_tableau(eng, dt)
     res, _ = eng.solve(lpamd.MAX_COST)
     assert res == dt.solve(lo.MAX_COST) == lpamd.SOLVED
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+def test_max_cost_run_after_a_max_reduction_run_that_ended(lpamd):
+    """A MAX_REDUCTION run that ends on a terminal status leaves its own scores in the partial buffers;
+    a MAX_COST run started afterwards must price afresh instead of trusting them (it would report
+    SOLVED on a tableau that still has positive reduced costs)."""
+    tab, dt = lo.from_text("max x1 + x2\nst\nx1 - x2 <= 1\nx1 >= 0\nx2 >= 0\n")
+    eng = lpamd.TableauEngine(tab.m, tab.N)
+    eng.upload(tab.T, tab.obj, tab.is_basic)
+    assert eng.run_pivots(lpamd.MAX_REDUCTION, -1)[0] == dt.solve(lo.MAX_REDUCTION) == lpamd.UNBOUNDED
+    assert eng.run_pivots(lpamd.MAX_COST, -1)[0] == dt.solve(lo.MAX_COST) == lpamd.UNBOUNDED
+    assert eng.run_pivots(lpamd.MAX_COST, 3)[0] == lpamd.UNBOUNDED
     assert eng.trace() == dt.trace()
     assert_same_tableau(eng, dt)
     eng.close()

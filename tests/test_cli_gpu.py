@@ -89,3 +89,34 @@ def test_solver_cli_revised_objective_on_goldens_outside_the_reference_ctest(nam
     assert out.stdout.rstrip("\n") == text.rstrip("\n")
     got = [tuple(map(int, l.split()[1:])) for l in out.stderr.splitlines() if l.startswith("pivot ")]
     assert got == rt.trace()
+
+
+@pytest.mark.parametrize("name,strategy,shards", [
+    ("test15", "max_cost", 2), ("test16", "max_reduction", 3), ("afiro", "max_cost", 4), ("kb2", "max_reduction", 2),
+    ("adlittle", "max_cost", 8), ("israel", "max_reduction", 3),
+])
+def test_solver_cli_column_shards_match_reference_golden(name, strategy, shards):
+    """`solver ... --shards K`: the C++ drop-in over K column shards (the multi-GPU code of
+    `--gpus N`, here with all shards on the one GPU): same golden text, same pivot sequence."""
+    out = subprocess.run([os.path.join(BIN, "solver"), _path(name), "simplex_tableau", strategy, "--trace", "--shards", str(shards)],
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.rstrip("\n") == case_golden(name, strategy).rstrip("\n")
+    _, dt = lo.from_text(case_text(name))
+    dt.solve(lo.STRATEGY[strategy])
+    got = [tuple(map(int, l.split()[1:])) for l in out.stderr.splitlines() if l.startswith("pivot ")]
+    assert got == dt.trace()
+
+
+def test_solver_cli_gpus_one_and_env(tmp_path):
+    """--gpus 1 and LPAMD_GPUS=1 are the single-engine path; --gpus beyond the visible GPUs fails loudly."""
+    golden = case_golden("test15", "max_cost").rstrip("\n")
+    out = subprocess.run([os.path.join(BIN, "solver"), _path("test15"), "simplex_tableau", "max_cost", "--gpus", "1"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.rstrip("\n") == golden
+    out = subprocess.run([os.path.join(BIN, "solver"), _path("test15"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, LPAMD_GPUS="1"))
+    assert out.returncode == 0 and out.stdout.rstrip("\n") == golden
+    out = subprocess.run([os.path.join(BIN, "solver"), _path("test15"), "simplex_tableau", "max_cost", "--gpus", "64"],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "visible" in out.stderr

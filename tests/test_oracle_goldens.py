@@ -117,3 +117,24 @@ def test_oracle_revised_objective_on_goldens_outside_the_reference_ctest(name):
     got_obj, want_obj = float(out.split("\n")[0]), float(want.split("\n")[0])
     assert abs(got_obj - want_obj) <= 1e-9 * abs(want_obj)
     assert [l.split(" = ")[0] for l in out.strip().split("\n")[1:]] == [l.split(" = ")[0] for l in want.strip().split("\n")[1:]]
+
+
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+@pytest.mark.parametrize("m,n,seed,k", [(60, 100, 1, 40), (300, 500, 3, 25), (17, 5, 2, 10), (200, 900, 7, 30), (1, 1, 1, 3)])
+def test_storage_free_oracle_equals_dense_oracle(strategy, m, n, seed, k):
+    """The restatement that regenerates every entry of the synthetic LP (used where the host cannot store
+    the tableau) walks the same pivots and leaves the same bits as the dense restatement."""
+    strat = lo.STRATEGY[strategy]
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    want = dt.solve(strat, max_pivots=k)
+    st = lo.StreamedSynthetic(m, n, seed, kmax=k)
+    got = st.run(strat, 3)                      # two legs: the state carries over
+    if got == lo.LIMIT:
+        got = st.run(strat, k)
+    trace, obj, rhs, basic = st.state()
+    assert got == want and trace == dt.trace()
+    u = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+    assert np.array_equal(u(obj), u(dt.obj)) and np.array_equal(u(rhs), u(dt.T[:, dt.N]))
+    assert np.array_equal(basic[: dt.N], dt.is_basic[: dt.N])
+    for j in sorted({0, n - 1, n, n + m - 1, n + m} | {e for e, _ in trace}):
+        assert np.array_equal(u(st.column(j)), u(dt.T[:, j])), "column %d" % j

@@ -56,6 +56,8 @@ def _worker(rank, world, port, case, strategy_name, out_dir, exchange):
     (("synthetic", 40, 90, 2), "max_reduction", "allreduce"),
     (("synthetic", 33, 64, 3), "max_cost", "broadcast"),
     (("synthetic", 33, 64, 3), "max_reduction", "broadcast"),
+    (("synthetic", 37, 70, 5), "max_cost", "fused"),          # the protocol of the library's own loop: one all-gather per pivot
+    (("synthetic", 40, 90, 2), "max_reduction", "fused"),
 ])
 def test_two_rank_loop_matches_oracle(tmp_path, case, strategy, exchange):
     _check_loop(tmp_path, case, strategy, exchange, 2)
@@ -70,6 +72,11 @@ def test_two_rank_lookahead_loop_other_chain_depths(tmp_path, monkeypatch, chain
 
 def test_four_rank_lookahead_loop_matches_oracle(tmp_path):
     _check_loop(tmp_path, ("synthetic", 37, 70, 5), "max_cost", "lookahead", 4)
+
+
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+def test_three_rank_fused_exchange_matches_oracle(tmp_path, strategy):
+    _check_loop(tmp_path, ("synthetic", 33, 64, 3), strategy, "fused", 3)
 
 
 def _check_loop(tmp_path, case, strategy, exchange, world):
@@ -115,6 +122,7 @@ def _solve_worker(rank, world, port, name, strategy_name, out_dir, exchange):
     ("test15", "max_cost", "allreduce", 2), ("test16", "max_reduction", "broadcast", 2),
     ("afiro", "max_cost", "allreduce", 3), ("test17", "max_reduction", "allreduce", 2),
     ("test15", "max_cost", "lookahead", 2), ("afiro", "max_cost", "lookahead", 3), ("test16", "max_cost", "lookahead", 2),
+    ("test15", "max_cost", "fused", 2), ("test17", "max_reduction", "fused", 3),
 ])
 def test_sharded_solve_with_feasibility_phase_matches_oracle_and_golden(tmp_path, name, strategy, exchange, world):
     """TableauSimplexSolve over shards, feasibility phase included: every rank walks the oracle's
