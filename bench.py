@@ -147,9 +147,11 @@ def main():
         sys.exit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # LPAMD_BENCH_FORCE_SHARDED=1 runs the sharded loop (RCCL all-gather included) for a world of one,
-    # to rehearse it on a one-GPU box; LPAMD_BENCH_SHARD="r/w" times shard r of a world of w alone.
-    force_sharded = os.environ.get("LPAMD_BENCH_FORCE_SHARDED", "0") == "1"
+    # LPAMD_BENCH_FORCE_SHARDED=1 runs the sharded loop (RCCL all-gather included) for a world of one, to
+    # rehearse it on a one-GPU box; LPAMD_BENCH_SHARD_OF=w times rank 0 of a w-GPU run alone (its shard, real
+    # RCCL launches, no wire time; the pivots are not the LP's, the work per pivot is that rank's).
+    shard_of = int(os.environ.get("LPAMD_BENCH_SHARD_OF", "0"))
+    force_sharded = os.environ.get("LPAMD_BENCH_FORCE_SHARDED", "0") == "1" or shard_of > 1
     use_dist = world > 1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -178,6 +180,8 @@ def main():
             ids = [lp.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
             group = lp.ShardGroup.join(m, N, rank, world, ids[0])
+        elif shard_of > 1:
+            group = lp.ShardGroup(m, N, shard_of, devices=[local_rank] * shard_of, rehearse_rank0=True)
         else:
             group = lp.ShardGroup(m, N, 1, devices=[local_rank])
         group.fill_synthetic(n, args.seed)
@@ -238,7 +242,8 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.config, "m": m, "n": n, "stored_columns": N + 1, "strategy": args.strategy,
                    "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world,
-                   "exchange": exchange, "pivots_per_pass": depth},
+                   "exchange": exchange, "pivots_per_pass": depth,
+                   **({"rehearsal": "rank 0 of a %d-GPU run alone on one GPU" % shard_of} if shard_of > 1 else {})},
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),
         "pivots_per_pass": round(pivots / max(passes, 1), 3),

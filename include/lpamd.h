@@ -253,7 +253,12 @@ int lpamd_poll(lpamd_engine* eng, int32_t* result);
  * Every lpamd_group_* call below is collective in that mode. */
 typedef struct lpamd_group lpamd_group;
 #define LPAMD_COMM_ID_BYTES 128
-enum { LPAMD_GROUP_LOCAL_EXCHANGE = 1 };
+enum {
+  LPAMD_GROUP_LOCAL_EXCHANGE = 1,
+  /* measurement aid: only shard 0 of the n_shards-way deal is created and trades with itself (RCCL world of
+   * one): the per-rank cost of an n_shards-GPU run on one GPU; the pivots are not those of the LP */
+  LPAMD_GROUP_REHEARSE_RANK0 = 2
+};
 int lpamd_comm_unique_id(void* id_out);
 int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards, const int32_t* devices, int32_t flags);
 int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id);

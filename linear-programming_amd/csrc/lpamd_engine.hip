@@ -75,7 +75,11 @@ struct lpamd_engine {
   int64_t rstride = 0;
   ChainStep* steps = nullptr;   // [kMaxChain]
   double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
-  int32_t* lists = nullptr;     // [2 * ncl]: columns touched by the steps so far, alternating per step
+  PassInfo* pass = nullptr;     // what the pass kernel has to do (k_chain_list)
+  int32_t* list_full = nullptr; // [ncl] columns every step of the chain touches ...
+  int32_t* list_part = nullptr; // [ncl] ... and columns some steps leave alone
+  double* rsl_full = nullptr;   // [ncl * chain_depth] row' values of the listed columns, one run per column
+  double* rsl_part = nullptr;
   int64_t slot_counter = 0;
   int device = 0;
   hipStream_t stream = nullptr;
@@ -93,7 +97,7 @@ struct lpamd_engine {
   double* cmin = nullptr;       // max-reduction pricing: per-column minimum ratio ...
   int64_t* crow = nullptr;      // ... its row (-1 none, -2 not a candidate) ...
   int64_t* pr_stamp = nullptr;  // ... and the pivot count for which the pair is valid
-  double* rhs_next = nullptr;   // right-hand side after the pivot being applied
+  double* rhs_next = nullptr;   // [chain_depth * lda] right-hand side after pivot s of the pass, s = 0..
   uint8_t* cand_next = nullptr; // pricing candidates after the pivot being applied
   Candidate* cand = nullptr;
   Candidate* cand_la = nullptr;   // look-ahead exchange: winner of the next pivot, written on the exchange stream
@@ -381,11 +385,11 @@ int enqueue_finalize(lpamd_engine* e, bool find_row, const Candidate* cand, cons
   if (find_row)
     hipLaunchKernelGGL(k_pivot_finalize<true>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
                        e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
-                       e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next);
+                       e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next, e->pass);
   else
     hipLaunchKernelGGL(k_pivot_finalize<false>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, cand, xcol, rv, ri,
                        e->n_ratio_part, e->n_row_blocks, d_override, e->st, e->colp, e->obj, e->is_basic, e->basis, e->rowp, e->active,
-                       e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next);
+                       e->trace, e->trace_cap, e->part_v, e->part_i, e->rhs_next, e->cand_next, e->pass);
   LP_TRY(check_launch("k_pivot_finalize"));
   e->price_partials_fresh = true;
   return LPAMD_OK;
@@ -401,43 +405,45 @@ int enqueue_finalize_update(lpamd_engine* e, bool find_row, const Candidate* can
 template <int kUnroll>
 void launch_update_chain(lpamd_engine* e, int grid, bool nt) {
   if (nt)
-    hipLaunchKernelGGL((k_update_chain<kUnroll, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
-                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis);
+    hipLaunchKernelGGL((k_update_chain<kUnroll, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->pass,
+                       e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis);
   else
-    hipLaunchKernelGGL((k_update_chain<kUnroll, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
-                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis);
+    hipLaunchKernelGGL((k_update_chain<kUnroll, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->pass,
+                       e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis);
 }
 
-// col' in registers: chains of 4 and 8, slab shape (kR, kC) chosen by e->slab_shape; false: not applicable
+// col' in registers: slab shape (kR, kC) chosen by e->slab_shape, chain length kK >= chain_depth; false: not applicable
 template <int kK, int kR, int kC>
 void launch_slab(lpamd_engine* e) {
   const int n_slabs = (int)(e->sh.lda / (2 * kUpdateThreads * kR));
   const int n_grp = std::max(1, std::min((e->ncl + kC - 1) / kC, std::max(1, e->slab_grid / n_slabs)));
   const int grid = n_slabs * n_grp;
   if (e->update_nt)
-    hipLaunchKernelGGL((k_update_slab<kK, kR, kC, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
-                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis, n_slabs);
+    hipLaunchKernelGGL((k_update_slab<kK, kR, kC, true>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->pass,
+                       e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis,
+                       n_slabs);
   else
-    hipLaunchKernelGGL((k_update_slab<kK, kR, kC, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->rowp,
-                       e->rstride, e->active, e->lists, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis, n_slabs);
+    hipLaunchKernelGGL((k_update_slab<kK, kR, kC, false>), dim3(grid), dim3(kUpdateThreads), 0, e->stream, e->T, e->sh.lda, e->colp, e->pass,
+                       e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis,
+                       n_slabs);
 }
 template <int kK>
 bool launch_slab_shape(lpamd_engine* e) {
   switch (e->slab_shape) {
     case 1: launch_slab<kK, 1, 8>(e); return true;
-    case 2: launch_slab<kK, 1, 16>(e); return true;
+    case 2: launch_slab<kK, 1, 4>(e); return true;
     case 3: if (e->sh.lda % 1024) return false; launch_slab<kK, 2, 4>(e); return true;
     case 4: if (e->sh.lda % 1024) return false; launch_slab<kK, 2, 8>(e); return true;
+    case 5: if (e->sh.lda % 1024) return false; launch_slab<kK, 2, 2>(e); return true;
     default: return false;
   }
 }
 bool launch_update_slab(lpamd_engine* e) {
-  if (e->chain_depth == 4) return launch_slab_shape<4>(e);
-  if (e->chain_depth == 8) return launch_slab_shape<8>(e);
-  if (e->chain_depth == 10) return launch_slab_shape<10>(e);
-  if (e->chain_depth == 12) return launch_slab_shape<12>(e);
-  if (e->chain_depth == 16) return launch_slab_shape<16>(e);
-  return false;
+  // the instantiated chain lengths; a chain shorter than the template takes the step-by-step path of the kernel
+  if (e->chain_depth <= 4) return launch_slab_shape<4>(e);
+  if (e->chain_depth <= 8) return launch_slab_shape<8>(e);
+  if (e->chain_depth <= 12) return launch_slab_shape<12>(e);
+  return launch_slab_shape<16>(e);
 }
 
 // Step j >= 1 of a chain: ratio partials (pricing fold + rebuilt column on one GPU; candidate record + column
@@ -448,14 +454,14 @@ int enqueue_chain_step(lpamd_engine* e, int j, const Candidate* xcand, double* x
   double* colv = xcol ? xcol : e->colv;
   if (xcol)
     hipLaunchKernelGGL(k_chain_ratio<true>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
-                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, colv, rv, ri, xcand);
+                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->rhs_next, colv, rv, ri, xcand);
   else
     hipLaunchKernelGGL(k_chain_ratio<false>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
-                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, colv, rv, ri, xcand);
+                       e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->rhs_next, colv, rv, ri, xcand);
   LP_TRY(check_launch("k_chain_ratio"));
   hipLaunchKernelGGL(k_chain_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
-                     e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, colv, e->obj, e->is_basic,
-                     e->basis, e->lists, e->trace, e->trace_cap, e->part_v, e->part_i);
+                     e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, colv, e->obj,
+                     e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i);
   LP_TRY(check_launch("k_chain_finalize"));
   e->price_partials_fresh = true;
   return LPAMD_OK;
@@ -483,6 +489,9 @@ int enqueue_chain_update(lpamd_engine* e) {
     e1 = e->ev[e->ev_used++];
     HIP_TRY(hipEventRecord(e0, e->stream));
   }
+  hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + 255) / 256)), dim3(256), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
+                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth);
+  LP_TRY(check_launch("k_chain_list"));
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
   const int grid = e->update_grid;
   if (launch_update_slab(e)) { /* col' in registers */ }
@@ -514,7 +523,7 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
     hipLaunchKernelGGL(k_pivot_setup_small, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->part_v + cur * kMaxPartials,
                        e->part_i + cur * kMaxPartials, e->n_price_part, e->n_row_blocks, e->st, slot, e->colp, e->obj, e->is_basic, e->basis,
                        e->rowp, e->active, e->trace, e->trace_cap, e->part_v + nxt * kMaxPartials, e->part_i + nxt * kMaxPartials, e->rhs_next,
-                       e->cand_next);
+                       e->cand_next, e->pass);
     LP_TRY(check_launch("k_pivot_setup_small"));
     e->price_buf = nxt;
     e->update_slot = slot;
@@ -685,14 +694,14 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
   // Longer columns: a pivot is bound by the HBM pass, so a chain of pivots shares one (see k_update_chain)
   // (column shards chain through lpamd_chain_step, the caller runs the exchange of every step)
-  e->chain_depth = !e->two_launch ? 8 : 1;
+  e->chain_depth = !e->two_launch ? 16 : 1;
   if (const char* env = getenv("LPAMD_CHAIN")) {
     e->chain_depth = std::max(1, std::min(kMaxChain, atoi(env)));
     if (e->chain_depth > 1) e->two_launch = false;
   }
-  // Measured (scripts/slab_sweep.sh, m=32768 n=65536, chain of 8): col' from L2 8.44 ms per pass; in registers with
-  // 512-row slabs x 8 columns in flight 6.68 ms, 1024-row slabs x 4 columns 5.68 ms (the HBM time of one pass again)
-  e->slab_shape = e->sh.lda % 1024 == 0 ? 3 : 1;
+  // Measured (m=32768 n=65536): col' from L2 8.44 ms per pass of 8 pivots; in registers, 1024-row slabs x 8 columns in
+  // flight 5.65 ms per pass of 16 pivots (the HBM time of one pass), x 4 columns 5.91 ms, 512-row slabs x 8 columns 6.64 ms
+  e->slab_shape = e->sh.lda % 1024 == 0 ? 4 : 1;
   if (const char* env = getenv("LPAMD_SLAB")) e->slab_shape = atoi(env);
   if (const char* env = getenv("LPAMD_SLAB_GRID")) e->slab_grid = std::max(1, atoi(env));
   if (hip_stream) {
@@ -712,15 +721,22 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->pr_stamp, sizeof(int64_t) * e->ncl));
-  HIP_TRY(hipMalloc(&e->rhs_next, sizeof(double) * e->sh.lda));
+  HIP_TRY(hipMalloc(&e->rhs_next, sizeof(double) * e->sh.lda * e->chain_depth));
   HIP_TRY(hipMalloc(&e->cand_next, e->ncl));
   HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
-  HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda, e->stream));
+  HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda * e->chain_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
   HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
   HIP_TRY(hipMalloc(&e->colv, sizeof(double) * e->sh.lda));
-  HIP_TRY(hipMalloc(&e->lists, sizeof(int32_t) * 2 * e->ncl));
+  HIP_TRY(hipMalloc(&e->pass, sizeof(PassInfo)));
+  HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
+  if (e->chain_depth > 1) {
+    HIP_TRY(hipMalloc(&e->list_full, sizeof(int32_t) * e->ncl));
+    HIP_TRY(hipMalloc(&e->list_part, sizeof(int32_t) * e->ncl));
+    HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)e->ncl * e->chain_depth));
+    HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->chain_depth));
+  }
   HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * e->sh.lda, e->stream));    // rows beyond m stay zero
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->cand_la, sizeof(Candidate)));
@@ -745,7 +761,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->lists};
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1190,11 +1206,13 @@ int lpamd_update_stats(lpamd_engine* e, double* total_ms, int64_t* launches, int
   LP_TRY(pull_state(e));
   e->prof_active = e->h_st.n_active;
   if (e->loop_depth > 1) {   // a pass that applied several pivots counts the columns of each
-    ChainStep cs[kMaxChain];
-    LP_TRY(read_local(e, e->steps, cs, sizeof(cs)));
-    for (int s = 1; s < e->loop_depth && cs[s].done; s++) e->prof_active += cs[s].n_touched;
+    PassInfo pi;
+    ChainStep c0;
+    LP_TRY(read_local(e, e->pass, &pi, sizeof(pi)));
+    LP_TRY(read_local(e, e->steps, &c0, sizeof(c0)));
+    if (pi.n_steps > 0) e->prof_active = pi.touched;
     // passes of different lengths (a budget that ends inside a chain): the average per pass since profiling began
-    if (cs[0].r > 0) e->prof_active = cs[0].e / cs[0].r;
+    if (c0.r > 0) e->prof_active = c0.e / c0.r;
   }
   if (total_ms) *total_ms = e->prof_ms;
   if (launches) *launches = e->prof_launches;
@@ -1234,9 +1252,9 @@ int lpamd_pass_stats(lpamd_engine* e, int32_t* pivots, int64_t* streamed_columns
   int32_t np = 1;
   int64_t streamed = e->h_st.n_active, touched = e->h_st.n_active;
   if (e->loop_depth > 1) {
-    ChainStep cs[kMaxChain];
-    LP_TRY(read_local(e, e->steps, cs, sizeof(cs)));
-    for (int s = 1; s < e->loop_depth && cs[s].done; s++) { np = s + 1; streamed = cs[s].n_list; touched += cs[s].n_touched; }
+    PassInfo pi;
+    LP_TRY(read_local(e, e->pass, &pi, sizeof(pi)));
+    if (pi.n_steps > 0) { np = pi.n_steps; streamed = pi.n_full + pi.n_part; touched = pi.touched; }
   }
   if (pivots) *pivots = np;
   if (streamed_columns) *streamed_columns = streamed;
@@ -1389,7 +1407,7 @@ int lpamd_lookahead_setup(lpamd_engine* e, const void* xbuf_dev) {
 
 int lpamd_chain_depth(const lpamd_engine* e, int32_t* depth) {
   if (!e || !depth) return set_err(LPAMD_E_ARG, "chain_depth: null argument");
-  *depth = std::min<int32_t>(e->chain_depth, kMaxChain - 1);
+  *depth = e->chain_depth;
   return LPAMD_OK;
 }
 
@@ -1397,7 +1415,7 @@ int lpamd_chain_step(lpamd_engine* e, void* xbuf_dev) {
   CHECK_LOADED(e);
   if (!xbuf_dev) return set_err(LPAMD_E_ARG, "chain_step: null exchange buffer");
   if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain_step: no pivot has been set up by lpamd_lookahead_setup");
-  if (e->pending_steps >= std::min<int32_t>(e->chain_depth, kMaxChain - 1))
+  if (e->pending_steps >= e->chain_depth)
     return set_err(LPAMD_E_STATE, "chain_step: the pass already holds %d pivots", e->pending_steps);
   e->apply_since_pull++;
   LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));

@@ -50,6 +50,27 @@ struct PivotState {  // device resident, one per engine
   double a, ce, f, g;
   int32_t n_active;  // local columns whose pivot-row entry is non-zero
   int32_t n_active2; // second counter of the two-launch loop (the counters alternate from pivot to pivot)
+  int32_t l_e, l_d;  // local columns of e and d on this rank (-1: another rank's, or none)
+};
+
+constexpr int kMaxChain = 16;   // pivots one pass over the tableau may apply
+
+struct ChainStep {   // pivots 1.. of the pass (pivot 0 is described by PivotState)
+  int32_t done;      // 1 once k_chain_finalize has set the step up
+  int32_t slot;      // column shards: rank whose slot delivered the entering column
+  int32_t l_in;      // local column of the entering variable (-1: another rank's)
+  int32_t l_out;     // local column of the leaving variable (-1: another rank's, or none)
+  int64_t e, r, d;
+  double a, ce, f, g;
+};
+
+// What k_chain_list leaves for the pass kernel.  Zeroed by the set-up of pivot 0 of every pass.
+struct PassInfo {
+  int32_t n_steps;   // pivots the pass applies
+  int32_t n_full;    // columns every step touches (row'_s != 0 for all s): list_full, no tests inside the pass
+  int32_t n_part;    // columns some steps leave alone: list_part
+  int32_t pad;
+  int64_t touched;   // sum over the steps of the columns each touches (the algorithmic count)
 };
 
 // The tableau shard: local column l lives in half[l & 1] at column slot l >> 1.
@@ -375,7 +396,7 @@ __device__ __forceinline__ void pivot_setup_body(
     double* __restrict__ colp, double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
     const int64_t* __restrict__ basis, double* __restrict__ rowp, int32_t* __restrict__ active,
     int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
-    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, double* s_v, int64_t* s_i) {
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, PassInfo* __restrict__ pass, double* s_v, int64_t* s_i) {
   const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
   const double* __restrict__ col = xcol ? xcol : T.col(eo / sh.world);
   const double a = col[r];
@@ -387,8 +408,9 @@ __device__ __forceinline__ void pivot_setup_body(
     for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
       const double cpi = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
       colp[i] = cpi;
-      // right-hand side after this pivot (the update applies the same formula to the RHS replica)
-      rhs_next[i] = flushz(__dadd_rn(rhs[i], __dmul_rn(cpi, rp_rhs)));
+      // right-hand side after this pivot (the update applies the same formula to the RHS replica, and
+      // leaves the column alone when its row' entry is exactly 0)
+      rhs_next[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs[i], __dmul_rn(cpi, rp_rhs))) : rhs[i];
     }
     return;
   }
@@ -439,6 +461,8 @@ __device__ __forceinline__ void pivot_setup_body(
     const int64_t d = d_now;
     st->e = e; st->r = r; st->d = d;
     st->a = a; st->ce = c.ce; st->f = f; st->g = g;
+    st->l_e = l_e; st->l_d = l_d;
+    pass->n_steps = 0; pass->n_full = 0; pass->n_part = 0; pass->touched = 0;   // filled by k_chain_list when the pass is a chain
     const int64_t it = st->iter;
     if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = r; }
     if (bump_iter) st->iter = it + 1;
@@ -453,7 +477,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
     double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
     double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
-    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next) {
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, PassInfo* __restrict__ pass) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
@@ -468,7 +492,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_finalize(
   }
   if (r < 0) { if (blockIdx.x == 0 && threadIdx.x == 0) st->status = ST_UNBOUNDED; return; }
   pivot_setup_body(T, sh, c, r, xcol, n_row_blocks, d_override, st, &st->n_active, true, colp, obj, is_basic, basis, rowp, active,
-                   trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, s_v, s_i);
+                   trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, pass, s_v, s_i);
 }
 
 // Two-launch MAX_COST iteration for short columns on one GPU (where a pivot is bound by launches,
@@ -488,7 +512,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_setup_small(
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
     double* __restrict__ rowp, int32_t* __restrict__ active, int64_t* __restrict__ trace, int64_t trace_cap,
     double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
-    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next) {
+    double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, PassInfo* __restrict__ pass) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
@@ -518,7 +542,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_setup_small(
   __syncthreads();
   if (r < 0) { if (lead) st->status = ST_UNBOUNDED; return; }
   pivot_setup_body(T, sh, c, r, nullptr, n_row_blocks, -1, st, slot ? &st->n_active2 : &st->n_active, false, colp, obj, is_basic, basis,
-                   rowp, active, trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, s_v, s_i);
+                   rowp, active, trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, pass, s_v, s_i);
 }
 
 // ------------------------------------------------------------ rank-1 update
@@ -661,55 +685,46 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
 // 16*m*n bytes of HBM traffic for the whole chain.  The chain ends early when the budget
 // is used up, at the optimum or when a column has no eligible row; the pass then applies
 // what has been set up and the next iteration of the loop reports the outcome exactly as
-// the one-pivot loop does.  Step s keeps col'_s at colp + s*lda and row'_s at rowp + s*rstride.
-constexpr int kMaxChain = 16;
-
-struct ChainStep {   // pivots 1.. of the pass (pivot 0 is described by PivotState)
-  int32_t done;      // 1 once k_chain_finalize has set the step up
-  int32_t n_touched; // local columns with row'_s != 0
-  int32_t n_list;    // length of the list of columns touched by steps 0..s
-  int32_t pad;
-  int64_t e, r, d;
-  double a, ce, f, g;
-};
-
+// the one-pivot loop does.  Step s keeps col'_s at colp + s*lda, row'_s at rowp + s*rstride and
+// the right-hand side after steps 0..s at rhsv + s*lda.
 // Record 0 is free (pivot 0 of a pass lives in PivotState) and keeps running totals over the passes
 // since profiling was switched on: e = columns touched summed over the pivots, r = passes,
-// d = columns streamed, a = pivots.  Written by the bookkeeping thread of the update kernel only.
-__device__ __forceinline__ void chain_account(ChainStep* steps, int n_steps, int n_active0, int n_list) {
-  int64_t touched = n_active0;
-  for (int s = 1; s < n_steps; s++) touched += steps[s].n_touched;
-  steps[0].e += touched;
+// d = columns streamed, a = pivots.  Written by the bookkeeping thread of the pass kernel only.
+__device__ __forceinline__ void chain_account(ChainStep* steps, const PassInfo& pass) {
+  steps[0].e += pass.touched;
   steps[0].r += 1;
-  steps[0].d += n_list;
-  steps[0].a += (double)n_steps;
+  steps[0].d += pass.n_full + pass.n_part;
+  steps[0].a += (double)pass.n_steps;
 }
 
-__device__ __forceinline__ double chain_apply(double v, int j, const double* __restrict__ colp, int64_t lda, int64_t i,
-                                              const double* rs) {
-#pragma unroll
-  for (int s = 0; s < kMaxChain - 1; s++)
-    if (s < j && rs[s] != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(colp[s * lda + i], rs[s])));   // the update leaves columns with row' == 0 alone
+// v as steps 0..j-1 leave it.  rs points at row'_0 of the entry's column (stride rstride between steps),
+// cs at col'_0 of its row (stride lda).  A step whose row' entry is exactly 0 leaves the column alone.
+__device__ __forceinline__ double chain_apply(double v, int j, const double* __restrict__ cs, int64_t lda,
+                                              const double* __restrict__ rs, int64_t rstride) {
+  for (int s = 0; s < j; s++) {
+    const double r = rs[s * rstride];
+    if (r != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(cs[s * lda], r)));
+  }
   return v;
 }
 
-// Step j >= 1: pricing fold on the objective row after step j-1, the entering column and the
-// right-hand side as steps 0..j-1 will leave them (column written to colv, the tableau is not
-// touched) and the ratio-test partials of reference lp_simplex_tableau.cc:207-227 on them.
+// Step j >= 1: pricing fold on the objective row after step j-1, the entering column as steps
+// 0..j-1 will leave it (written to colv, the tableau is not touched) and the ratio-test partials of
+// reference lp_simplex_tableau.cc:207-227 on it and on the right-hand side after step j-1.
 // kExternal (column shards): the entering column has been chosen among all ranks and arrives,
 // already rebuilt by its owner, in `colv` together with the candidate record `xcand`.
 template <bool kExternal>
 __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
     const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
-    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const double* __restrict__ rhsv,
     double* __restrict__ colv, double* __restrict__ rv, int64_t* __restrict__ ri, const Candidate* __restrict__ xcand) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   if (j == 1) {
-    if (lead) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].n_touched = 0; steps[s].n_list = 0; steps[s].e = -1; }
+    if (lead) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
   } else if (!steps[j - 1].done) {
     return;                               // the chain ended before this step
   }
@@ -726,13 +741,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     if (lead) { steps[j].e = gcol_of(l * sh.world + sh.rank, sh.N); steps[j].ce = ce; }
   }
   const double* __restrict__ col = T.col(l);
-  const double* __restrict__ rhs = T.col(sh.nloc);
-  double rs_c[kMaxChain - 1], rs_b[kMaxChain - 1];
-#pragma unroll
-  for (int s = 0; s < kMaxChain - 1; s++) {
-    rs_c[s] = (!kExternal && s < j) ? rowp[s * rstride + l] : 0.0;
-    rs_b[s] = s < j ? rowp[s * rstride + sh.nloc] : 0.0;
-  }
+  const double* __restrict__ rhs = rhsv + (int64_t)(j - 1) * sh.lda;
   double bv = DBL_MAX;
   int64_t bi = -1;
   for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
@@ -740,12 +749,11 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     if (kExternal) {
       a = colv[i];
     } else {
-      a = chain_apply(col[i], j, colp, sh.lda, i, rs_c);
+      a = chain_apply(col[i], j, colp + i, sh.lda, rowp + l, rstride);
       colv[i] = a;
     }
     if ((float)a > -1e-6f) continue;
-    const double b = chain_apply(rhs[i], j, colp, sh.lda, i, rs_b);
-    const double ratio = b / (-a);
+    const double ratio = rhs[i] / (-a);
     if (bv > ratio) { bv = ratio; bi = i; }
   }
   block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
@@ -753,16 +761,15 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
 }
 
 // Set-up of step j (reference lp_simplex_tableau.cc:10-44 on the tableau after step j-1): row
-// fold, scalars, col'_j, the pivot row gathered with steps 0..j-1 applied on the fly, row'_j,
-// the objective row, the list of columns any step so far touches (lists of successive steps
-// alternate between two buffers), the pricing partials of the iteration after this step.
-// PivotState keeps describing pivot 0 until the update kernel has used it.
+// fold, scalars, col'_j, the right-hand side after the step, the pivot row gathered with steps
+// 0..j-1 applied on the fly, row'_j, the objective row, the pricing partials of the iteration after
+// this step.  PivotState keeps describing pivot 0 until the pass kernel has used it.
 __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
     const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
-    double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, const double* __restrict__ colv,
+    double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, double* __restrict__ rhsv, const double* __restrict__ colv,
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
-    int32_t* __restrict__ lists, int64_t* __restrict__ trace, int64_t trace_cap,
+    int64_t* __restrict__ trace, int64_t trace_cap,
     double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
@@ -779,9 +786,15 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
   if ((int)blockIdx.x < n_row_blocks) {
-    double* __restrict__ cj = colp + j * sh.lda;
-    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads)
-      cj[i] = (i == r2) ? __dadd_rn(1.0, a2) : colv[i];
+    double* __restrict__ cj = colp + (int64_t)j * sh.lda;
+    const double* __restrict__ rhs_prev = rhsv + (int64_t)(j - 1) * sh.lda;
+    double* __restrict__ rhs_now = rhsv + (int64_t)j * sh.lda;
+    const double rp_rhs = __dmul_rn(rhs_prev[r2], f2);   // row'_j of the right-hand-side column
+    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
+      const double cpi = (i == r2) ? __dadd_rn(1.0, a2) : colv[i];
+      cj[i] = cpi;
+      rhs_now[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs_prev[i], __dmul_rn(cpi, rp_rhs))) : rhs_prev[i];
+    }
     return;
   }
   const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
@@ -791,70 +804,40 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     const int64_t o = ordinal_of(g, sh.N);
     return (o % sh.world == sh.rank) ? (int)(o / sh.world) : -1;
   };
-  // entering / leaving columns of steps 0..j-1 and the basic variable of row r2 after them
-  int l_in[kMaxChain], l_out[kMaxChain];
-  double c_r[kMaxChain - 1];       // col'_s[r2]
-  int64_t d2 = basis[r2];          // basis[] is flipped by the update kernel
-#pragma unroll
-  for (int s = 0; s < kMaxChain - 1; s++) {
-    l_in[s] = l_out[s] = -1;
-    c_r[s] = 0.0;
-    if (s < j) {
-      const int64_t es = s == 0 ? st->e : steps[s].e, ds = s == 0 ? st->d : steps[s].d, rs = s == 0 ? st->r : steps[s].r;
-      l_in[s] = local_id(es);
-      l_out[s] = local_id(ds);
-      c_r[s] = colp[s * sh.lda + r2];
-      if (rs == r2) d2 = es;
-    }
-  }
+  // the basic variable of row r2 after steps 0..j-1 (basis[] is flipped by the pass kernel)
+  int64_t d2 = basis[r2];
+  if (st->r == r2) d2 = st->e;
+  for (int s = 1; s < j; s++)
+    if (steps[s].r == r2) d2 = steps[s].e;
   const int l_e2 = local_id(e2), l_d2 = local_id(d2);
-  int32_t* __restrict__ list = lists + (size_t)(j & 1) * ncl;
+  const double* __restrict__ c_r = colp + r2;       // col'_s[r2] at c_r[s * lda]
   double nbv = -DBL_MAX;
   int64_t nbi = -1;
   for (int l0 = cb * kPartialThreads; l0 < ncl; l0 += n_cb * kPartialThreads) {
     const int l = l0 + threadIdx.x;
-    bool act = false, second = false;
     if (l < ncl) {
-      double t = T.col(l)[r2];
-      bool basic = l < sh.nloc && is_basic[l] != 0;
-#pragma unroll
-      for (int s = 0; s < kMaxChain - 1; s++) {
-        if (s < j) {
-          const double rs = rowp[s * rstride + l];
-          if (rs != 0.0) { t = flushz(__dadd_rn(t, __dmul_rn(c_r[s], rs))); act = true; }
-          if (l == l_in[s]) basic = true; else if (l == l_out[s]) basic = false;
-        }
-      }
+      const double t = chain_apply(T.col(l)[r2], j, c_r, sh.lda, rowp + l, rstride);
       const double rp2 = __dmul_rn(t, f2);
       double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g2)));
       if (l == l_e2) o = 0.0;
       obj[l] = o;
-      rowp[j * rstride + l] = rp2;
-      second = rp2 != 0.0;
-      act = act || second;
+      rowp[(int64_t)j * rstride + l] = rp2;
       if (l < sh.nloc) {
+        bool basic = is_basic[l] != 0;               // flags as before the pass, then the steps set up so far
+        if (l == st->l_e) basic = true; else if (l == st->l_d) basic = false;
+        for (int s = 1; s < j; s++) {
+          if (l == steps[s].l_in) basic = true; else if (l == steps[s].l_out) basic = false;
+        }
         if (l == l_e2) basic = true; else if (l == l_d2) basic = false;
         if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
       }
-    }
-    const unsigned long long mask = __ballot(act);
-    const unsigned long long mask2 = __ballot(second);
-    if (mask) {
-      const int lane = threadIdx.x & (kWave - 1);
-      const int leader = __ffsll((long long)mask) - 1;
-      int base = 0;
-      if (lane == leader) {
-        base = atomicAdd(&steps[j].n_list, __popcll(mask));
-        if (mask2) atomicAdd(&steps[j].n_touched, __popcll(mask2));
-      }
-      base = __shfl(base, leader, kWave);
-      if (act) list[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
     }
   }
   block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
   if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
   if (cb == 0 && threadIdx.x == 0) {
     steps[j].r = r2; steps[j].d = d2; steps[j].a = a2; steps[j].f = f2; steps[j].g = g2;
+    steps[j].l_in = l_e2; steps[j].l_out = l_d2;
     steps[j].done = 1;
     const int64_t it = st->iter;
     if (it < trace_cap) { trace[2 * it] = e2; trace[2 * it + 1] = r2; }
@@ -862,44 +845,86 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   }
 }
 
-// The pass itself: pivot 0 alone over its own list, or the whole chain over the list of its last step.
-template <int kUnroll, bool kNT>
-__global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
-    Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
-    const int32_t* __restrict__ active, const int32_t* __restrict__ lists, int depth,
-    PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
-    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
+// Once per pass, after the last set-up: the columns the pass has to stream, split into those that
+// every step touches (list_full; the pass applies the chain to them without a single test) and those
+// that some step leaves alone (list_part: entering and leaving columns of the chain, mostly), and
+// the row' values of every listed column side by side (rsl_*[k * stride + s] = row'_s of the k-th
+// listed column, zero beyond the chain), which the pass reads as one short run per column.
+__global__ __launch_bounds__(256) void k_chain_list(
+    const double* __restrict__ rowp, int64_t rstride, int depth, const ChainStep* __restrict__ steps,
+    const PivotState* __restrict__ st, int ncl, PassInfo* __restrict__ pass,
+    int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride) {
   if (st->status != ST_RUNNING) return;
   int n_steps = 1;
   while (n_steps < depth && steps[n_steps].done) n_steps++;
-  const int n_list = n_steps > 1 ? steps[n_steps - 1].n_list : st->n_active;
-  const int32_t* __restrict__ list = n_steps > 1 ? lists + (size_t)((n_steps - 1) & 1) * (sh.nloc + 1) : active;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    // bookkeeping of reference lp_simplex_tableau.cc:16-28, pivot after pivot
-    auto flip = [&](int64_t e, int64_t d, int64_t r) {
-      const int64_t eo = ordinal_of(e, sh.N);
-      if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
-      if (d >= 0 && d != sh.N) {
-        const int64_t dord = ordinal_of(d, sh.N);
-        if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
-      }
-      basis[r] = e;
-    };
-    flip(st->e, st->d, st->r);
-    for (int s = 1; s < n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
-    chain_account(steps, n_steps, st->n_active, n_list);
-    if (n_steps > 1) {   // no other workgroup of this launch reads these fields
-      const ChainStep& z = steps[n_steps - 1];
-      st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
-    }
+  if (blockIdx.x == 0 && threadIdx.x == 0) pass->n_steps = n_steps;
+  const int l = blockIdx.x * blockDim.x + threadIdx.x;
+  int nz = 0;
+  if (l < ncl)
+    for (int s = 0; s < n_steps; s++) nz += rowp[s * rstride + l] != 0.0 ? 1 : 0;
+  const bool full = nz == n_steps, part = nz > 0 && !full;
+  const int lane = threadIdx.x & (kWave - 1);
+  const unsigned long long mf = __ballot(full), mp = __ballot(part);
+  int bf = 0, bp = 0;
+  if (lane == 0) {
+    if (mf) bf = atomicAdd(&pass->n_full, __popcll(mf));
+    if (mp) bp = atomicAdd(&pass->n_part, __popcll(mp));
   }
+  bf = __shfl(bf, 0, kWave);
+  bp = __shfl(bp, 0, kWave);
+  int total = nz;
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kWave);
+  if (lane == 0 && total) atomicAdd((unsigned long long*)&pass->touched, (unsigned long long)total);
+  if (full || part) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int k = full ? bf + __popcll(mf & below) : bp + __popcll(mp & below);
+    (full ? list_full : list_part)[k] = l;
+    double* __restrict__ out = (full ? rsl_full : rsl_part) + (int64_t)k * stride;
+    for (int s = 0; s < stride; s++) out[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
+  }
+}
+
+// Bookkeeping of reference lp_simplex_tableau.cc:16-28 for every pivot of the pass (one thread).
+__device__ __forceinline__ void chain_bookkeeping(PivotState* st, ChainStep* steps, const PassInfo& pass, const Shape& sh,
+                                                  uint8_t* is_basic, int64_t* basis) {
+  auto flip = [&](int64_t e, int64_t d, int64_t r) {
+    const int64_t eo = ordinal_of(e, sh.N);
+    if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+    if (d >= 0 && d != sh.N) {
+      const int64_t dord = ordinal_of(d, sh.N);
+      if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+    }
+    basis[r] = e;
+  };
+  flip(st->e, st->d, st->r);
+  for (int s = 1; s < pass.n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
+  chain_account(steps, pass);
+  if (pass.n_steps > 1) {   // no other workgroup of the launch reads these fields
+    const ChainStep& z = steps[pass.n_steps - 1];
+    st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
+  }
+}
+
+// The pass with the col' vectors read from L2 per column (any chain length, any column length).
+template <int kUnroll, bool kNT>
+__global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
+    Tab T, int64_t lda, const double* __restrict__ colp, const PassInfo* __restrict__ passp,
+    const int32_t* __restrict__ list_full, const int32_t* __restrict__ list_part,
+    const double* __restrict__ rsl_full, const double* __restrict__ rsl_part, int stride,
+    PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
+    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis) {
+  if (st->status != ST_RUNNING) return;
+  const PassInfo pass = *passp;
+  if (pass.n_steps <= 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) chain_bookkeeping(st, steps, pass, sh, is_basic, basis);
   const int n_vec = (int)(lda / 2);
   const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
+  const int n_list = pass.n_full + pass.n_part;
   for (int k = blockIdx.x; k < n_list; k += gridDim.x) {
-    const int l = list[k];
-    double rs[kMaxChain];   // uniform over the workgroup
-#pragma unroll
-    for (int s = 0; s < kMaxChain; s++) rs[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
+    const bool in_full = k < pass.n_full;
+    const int l = in_full ? list_full[k] : list_part[k - pass.n_full];
+    const double* __restrict__ rs = in_full ? rsl_full + (int64_t)k * stride : rsl_part + (int64_t)(k - pass.n_full) * stride;
     double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l));
     int v = threadIdx.x;
     for (; v + (kUnroll - 1) * kUpdateThreads < n_vec; v += kUnroll * kUpdateThreads) {
@@ -907,11 +932,11 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
 #pragma unroll
       for (int u = 0; u < kUnroll; u++) t[u] = ld16<kNT>(p + v + u * kUpdateThreads);
       __builtin_amdgcn_sched_barrier(0);   // all loads of the batch before its first store
+      for (int s = 0; s < pass.n_steps; s++) {
+        const double r = rs[s];
+        if (r != 0.0) {
 #pragma unroll
-      for (int s = 0; s < kMaxChain; s++) {
-        if (rs[s] != 0.0) {
-#pragma unroll
-          for (int u = 0; u < kUnroll; u++) t[u] = rank1(t[u], cp[s * n_vec + v + u * kUpdateThreads], rs[s]);
+          for (int u = 0; u < kUnroll; u++) t[u] = rank1(t[u], cp[s * n_vec + v + u * kUpdateThreads], r);
         }
       }
 #pragma unroll
@@ -919,9 +944,10 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
     }
     for (; v < n_vec; v += kUpdateThreads) {
       double2 o = ld16<kNT>(p + v);
-#pragma unroll
-      for (int s = 0; s < kMaxChain; s++)
-        if (rs[s] != 0.0) o = rank1(o, cp[s * n_vec + v], rs[s]);
+      for (int s = 0; s < pass.n_steps; s++) {
+        const double r = rs[s];
+        if (r != 0.0) o = rank1(o, cp[s * n_vec + v], r);
+      }
       st16<kNT>(p + v, o);
     }
   }
@@ -930,39 +956,31 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
 // The same pass with the col' vectors in REGISTERS.  k_update_chain re-reads every col'_s per
 // column from L2 (8 bytes per entry and step next to the 16 bytes of HBM traffic), which limits a
 // long chain.  Here a workgroup owns a slab of 512*kR rows, keeps its kK slices of col' in
-// registers and walks the column list, kC columns (kR*kC 16-byte loads per lane) in flight; row'
-// values are uniform per column.  Fast path: full chain and every step touches all kC columns (no
-// branches inside); anything else (shorter chain, a column some step leaves alone, the tail of the
-// list) takes the per-step tests of k_update_chain.  Needs lda % (512*kR) == 0.
+// registers and walks the column lists, kC columns (kR*kC 16-byte loads per lane, all issued before
+// the first store) in flight; the row' values of a column are one run of scalars (rsl_*), fetched
+// when its turn comes.
+//
+// Full chain over list_full: no test per step.  The drop of |v| < 1e-6 after every add (reference
+// lp_simplex_tableau.cc:5-8) is taken out of the inner loop: the chain is first evaluated WITHOUT
+// the drop while the smallest |v| seen on the way is tracked (multiply, add, minimum: three
+// instructions per entry and step instead of five).  If no lane saw a value below the threshold,
+// no drop would have happened and the result is exactly the reference's; otherwise the wavefront
+// redoes that column from the loaded values with the drop in place.  A drop is rare (the entering
+// column of every step takes it, hardly anything else in a dense tableau).
+// Everything else (a shorter chain, list_part, the tail of list_full) takes the step-by-step path.
+// Needs lda % (512*kR) == 0.
 template <int kK, int kR, int kC, bool kNT>
 __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
-    Tab T, int64_t lda, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
-    const int32_t* __restrict__ active, const int32_t* __restrict__ lists, int depth,
+    Tab T, int64_t lda, const double* __restrict__ colp, const PassInfo* __restrict__ passp,
+    const int32_t* __restrict__ list_full, const int32_t* __restrict__ list_part,
+    const double* __restrict__ rsl_full, const double* __restrict__ rsl_part, int stride,
     PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
     uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis, int n_slabs) {
   if (st->status != ST_RUNNING) return;
-  int n_steps = 1;
-  while (n_steps < depth && steps[n_steps].done) n_steps++;
-  const int n_list = n_steps > 1 ? steps[n_steps - 1].n_list : st->n_active;
-  const int32_t* __restrict__ list = n_steps > 1 ? lists + (size_t)((n_steps - 1) & 1) * (sh.nloc + 1) : active;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    auto flip = [&](int64_t e, int64_t d, int64_t r) {
-      const int64_t eo = ordinal_of(e, sh.N);
-      if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
-      if (d >= 0 && d != sh.N) {
-        const int64_t dord = ordinal_of(d, sh.N);
-        if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
-      }
-      basis[r] = e;
-    };
-    flip(st->e, st->d, st->r);
-    for (int s = 1; s < n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
-    chain_account(steps, n_steps, st->n_active, n_list);
-    if (n_steps > 1) {
-      const ChainStep& z = steps[n_steps - 1];
-      st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
-    }
-  }
+  const PassInfo pass = *passp;
+  const int n_steps = pass.n_steps;
+  if (n_steps <= 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) chain_bookkeeping(st, steps, pass, sh, is_basic, basis);
   const int n_vec = (int)(lda / 2);
   const int slab = blockIdx.x % n_slabs, grp = blockIdx.x / n_slabs, n_grp = gridDim.x / n_slabs;
   const int v0 = slab * (kUpdateThreads * kR) + threadIdx.x;
@@ -975,53 +993,78 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
       c[s][r].x = c[s][r].y = 0.0;
       if (s < n_steps) c[s][r] = cp[s * n_vec + v0 + r * kUpdateThreads];
     }
-  for (int k0 = grp * kC; k0 < n_list; k0 += n_grp * kC) {
-    double2* p[kC];
-    double rs[kC][kK];
-    bool fast = n_steps == kK && k0 + kC <= n_list;
+  const double kDrop = (double)1e-6f;
+  int k0 = grp * kC;
+  if (n_steps == kK) {
+    for (; k0 + kC <= pass.n_full; k0 += n_grp * kC) {
+      double2* p[kC];
+      double2 t[kC][kR];
 #pragma unroll
-    for (int u = 0; u < kC; u++) {
-      const bool valid = k0 + u < n_list;
-      const int l = valid ? list[k0 + u] : 0;
-      p[u] = valid ? reinterpret_cast<double2*>(T.col(l)) + v0 : nullptr;
-#pragma unroll
-      for (int s = 0; s < kK; s++) {
-        rs[u][s] = (valid && s < n_steps) ? rowp[s * rstride + l] : 0.0;
-        fast = fast && rs[u][s] != 0.0;
-      }
-    }
-    double2 t[kC][kR];
-    if (fast) {
-#pragma unroll
-      for (int u = 0; u < kC; u++)
+      for (int u = 0; u < kC; u++) {
+        p[u] = reinterpret_cast<double2*>(T.col(list_full[k0 + u])) + v0;
 #pragma unroll
         for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);
+      }
       __builtin_amdgcn_sched_barrier(0);   // all loads of the batch before its first store
 #pragma unroll
       for (int u = 0; u < kC; u++) {
-#pragma unroll
-        for (int s = 0; s < kK; s++)
-#pragma unroll
-          for (int r = 0; r < kR; r++) t[u][r] = rank1(t[u][r], c[s][r], rs[u][s]);
-#pragma unroll
-        for (int r = 0; r < kR; r++) st16<kNT>(p[u] + r * kUpdateThreads, t[u][r]);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < kC; u++) {
-        if (p[u] == nullptr) continue;
-#pragma unroll
-        for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);
+        const double* __restrict__ rs = rsl_full + (int64_t)(k0 + u) * stride;
+        double mx = DBL_MAX, my = DBL_MAX;
 #pragma unroll
         for (int s = 0; s < kK; s++) {
-          if (rs[u][s] != 0.0) {
+          const double rj = rs[s];
 #pragma unroll
-            for (int r = 0; r < kR; r++) t[u][r] = rank1(t[u][r], c[s][r], rs[u][s]);
+          for (int r = 0; r < kR; r++) {
+            t[u][r].x = __dadd_rn(t[u][r].x, __dmul_rn(c[s][r].x, rj));
+            t[u][r].y = __dadd_rn(t[u][r].y, __dmul_rn(c[s][r].y, rj));
+            mx = fmin(mx, fabs(t[u][r].x));
+            my = fmin(my, fabs(t[u][r].y));
+          }
+        }
+        if (__any(fmin(mx, my) < kDrop)) {   // a value below the threshold on the way: this column again, with the drop
+#pragma unroll
+          for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);   // not stored yet
+          // row' is fetched again through an offset the compiler cannot see through: otherwise it keeps all the
+          // products of the loop above alive for this rare path, which doubles the register count
+          int zero;
+          asm volatile("s_mov_b32 %0, 0" : "=s"(zero));
+          const double* __restrict__ rs2 = rs + zero;
+#pragma unroll
+          for (int s = 0; s < kK; s++) {   // fully unrolled: col' must stay in registers
+            const double rj = rs2[s];
+#pragma unroll
+            for (int r = 0; r < kR; r++) t[u][r] = rank1(t[u][r], c[s][r], rj);
           }
         }
 #pragma unroll
         for (int r = 0; r < kR; r++) st16<kNT>(p[u] + r * kUpdateThreads, t[u][r]);
       }
+    }
+  }
+  // step by step: what is left of list_full (all of it when the chain is shorter than kK), then list_part
+  const int n_list = pass.n_full + pass.n_part;
+  for (; k0 < n_list; k0 += n_grp * kC) {
+#pragma unroll 1
+    for (int u = 0; u < kC; u++) {
+      const int k = k0 + u;
+      if (k >= n_list) break;
+      const bool in_full = k < pass.n_full;
+      const int l = in_full ? list_full[k] : list_part[k - pass.n_full];
+      const double* __restrict__ rs = in_full ? rsl_full + (int64_t)k * stride : rsl_part + (int64_t)(k - pass.n_full) * stride;
+      double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l)) + v0;
+      double2 w[kR];
+#pragma unroll
+      for (int r = 0; r < kR; r++) w[r] = ld16<kNT>(p + r * kUpdateThreads);
+#pragma unroll
+      for (int s = 0; s < kK; s++) {
+        const double rj = s < n_steps ? rs[s] : 0.0;
+        if (rj != 0.0) {
+#pragma unroll
+          for (int r = 0; r < kR; r++) w[r] = rank1(w[r], c[s][r], rj);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kR; r++) st16<kNT>(p + r * kUpdateThreads, w[r]);
     }
   }
 }
@@ -1101,13 +1144,9 @@ __global__ __launch_bounds__(kPartialThreads) void k_export_lookahead(
   if (i >= sh.lda) return;
   double v = 0.0;
   if (l >= 0 && i < sh.m) {
-    v = T.col(l)[i];
     int n = pending > 0 ? 1 : 0;
     while (n > 0 && n < pending && steps[n].done) n++;
-    double rs[kMaxChain - 1];
-#pragma unroll
-    for (int s = 0; s < kMaxChain - 1; s++) rs[s] = s < n ? rowp[s * rstride + l] : 0.0;
-    v = chain_apply(v, n, colp, sh.lda, i, rs);          // the update leaves columns with row' == 0 alone
+    v = chain_apply(T.col(l)[i], n, colp + i, sh.lda, rowp + l, rstride);   // the update leaves columns with row' == 0 alone
   }
   xlocal[i] = v;
 }

@@ -203,7 +203,8 @@ struct lpamd_shard {   // one column shard of a group and its exchange state
 
 struct lpamd_group {
   int64_t m = 0, N = 0, lda = 0, slot_words = 0, wide = 0;
-  int world = 1;
+  int world = 1;                  // ranks of the exchange
+  int engine_world = 1;           // shards the columns are dealt over (differs from world only in a rehearsal)
   bool local_exchange = false;
   bool inline_exchange = true;    // collectives inside a chain run on the engine's stream (nothing to overlap them with)
   int chain = 1;                  // pivots per pass of the look-ahead loop
@@ -565,7 +566,7 @@ int init_shard(Group* g, Shard& s, int rank, int device) {
   s.rank = rank;
   s.device = device;
   HIP_TRY(hipSetDevice(device));
-  LP_TRY(lpamd_create(&s.eng, g->m, g->N, rank, g->world, nullptr));
+  LP_TRY(lpamd_create(&s.eng, g->m, g->N, rank, g->engine_world, nullptr));
   HIP_TRY(hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking));
   for (hipEvent_t* ev : {&s.ev_sent, &s.ev_arrived, &s.ev_pub, &s.ev_read}) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
   HIP_TRY(hipMalloc(&s.slot, sizeof(uint64_t) * g->slot_words));
@@ -586,6 +587,7 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   g->m = m;
   g->N = N;
   g->world = world;
+  g->engine_world = world;
   g->lda = lpamd_exchange_bytes(m) / (int64_t)sizeof(double);
   if (const char* env = getenv("LPAMD_LDA_PAD")) g->lda += round_up(std::max(0, atoi(env)), kSlabRows);
   g->slot_words = kSlotHeaderWords + g->lda;
@@ -633,7 +635,7 @@ int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
   const bool local = (flags & LPAMD_GROUP_LOCAL_EXCHANGE) != 0;
   std::vector<int> devs(n_shards);
-  for (int k = 0; k < n_shards; k++) {
+  for (int k = 0; k < ((flags & LPAMD_GROUP_REHEARSE_RANK0) ? 1 : n_shards); k++) {
     devs[k] = devices ? devices[k] : k;
     if (devs[k] < 0 || devs[k] >= ndev) return set_err(LPAMD_E_NODEVICE, "group_create: shard %d wants device %d, %d visible", k, devs[k], ndev);
     for (int q = 0; q < k && !local; q++)
@@ -641,7 +643,13 @@ int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards
   }
   int prev = 0;
   (void)hipGetDevice(&prev);
+  // Rehearsal: only rank 0 of the deal exists and trades with itself; the work per pivot is that of one rank
+  // of an n_shards-GPU run (the pivots are not the LP's: the other ranks' candidates are missing).
+  const bool rehearse = (flags & LPAMD_GROUP_REHEARSE_RANK0) != 0;
+  const int engine_world = n_shards;
+  if (rehearse) { n_shards = 1; devs.resize(1); }
   Group* g = new_group(m, N, n_shards, flags);
+  g->engine_world = engine_world;
   g->shards.resize(n_shards);
   int rc = LPAMD_OK;
   for (int k = 0; k < n_shards && rc == LPAMD_OK; k++) rc = init_shard(g, g->shards[k], k, devs[k]);

@@ -394,7 +394,7 @@ class ShardGroup:
     process (local_exchange=True: device copies instead of RCCL, shards may share a GPU);
     ShardGroup.join(m, N, rank, world, comm_id) is the one-process-per-GPU form."""
 
-    def __init__(self, m, N, n_shards=1, devices=None, local_exchange=False, _joined=None):
+    def __init__(self, m, N, n_shards=1, devices=None, local_exchange=False, rehearse_rank0=False, _joined=None):
         self.L = library()
         self.m, self.N = int(m), int(N)
         self.h = ctypes.c_void_p()
@@ -405,7 +405,8 @@ class ShardGroup:
             dev = None
             if devices is not None:
                 dev = (ctypes.c_int32 * int(n_shards))(*[int(d) for d in devices])
-            _ck(self.L.lpamd_group_create(ctypes.byref(self.h), self.m, self.N, int(n_shards), dev, 1 if local_exchange else 0))
+            flags = (1 if local_exchange else 0) | (2 if rehearse_rank0 else 0)
+            _ck(self.L.lpamd_group_create(ctypes.byref(self.h), self.m, self.N, int(n_shards), dev, flags))
         a, b = ctypes.c_int32(), ctypes.c_int32()
         _ck(self.L.lpamd_group_shards(self.h, ctypes.byref(a), ctypes.byref(b)))
         self.n_local, self.world = a.value, b.value
