@@ -286,6 +286,22 @@ int lpamd_group_objective_constant(lpamd_group* g, double* out);
 int lpamd_group_pivot_count(lpamd_group* g, int64_t* n);
 int lpamd_group_trace(lpamd_group* g, int64_t* e, int64_t* r, int64_t cap, int64_t* n);
 
+/* ---- allocation-free ratio test -------------------------------------------
+ * No counterpart in the reference.  For callers that cannot allocate device memory: code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  It is the
+ * MAX_COST ratio test of lpamd_ratio_test (reference lp_simplex_tableau.cc:207-227: rows with
+ * (float)a <= -1e-6f, ratio b / (-a), strict minimum, lowest row on ties) on two device vectors
+ * the caller owns: col_dev = the entering column, rhs_dev = the right-hand side, m doubles each.
+ * *row_out_dev (device memory) receives the pivot row, or -1 if no row is eligible (unbounded);
+ * *ratio_out_dev (device memory, may be NULL) its ratio.  The call is asynchronous on
+ * `hip_stream` (NULL = the default stream of the current device) and calls no hipMalloc /
+ * hipFree: the per-workgroup partial results live in a 16 KiB array inside the library, one copy
+ * per GPU.  Limits: 1 <= m <= 16777216 (LPAMD_E_ARG beyond).  All calls on one GPU share that
+ * array: calls that overlap on one GPU (two streams, two host threads) race; calls issued on one
+ * stream are ordered. */
+int lpamd_ratio_test_noalloc(const double* col_dev, const double* rhs_dev, int64_t m, int64_t* row_out_dev,
+                             double* ratio_out_dev, void* hip_stream);
+
 /* ---- revised simplex on the tableau (one GPU) ------------------------------
  * The reference's other tableau algorithm, `solver <file> revised_simplex_tableau`
  * (reference solver.cc:139-144): the tableau stays as uploaded and a dense basis

@@ -1447,4 +1447,5 @@ int lpamd_poll(lpamd_engine* e, int32_t* result) {
 }  // extern "C"
 
 #include "lpamd_revised.hip.h"
+#include "lpamd_noalloc.hip.h"
 #include "lpamd_sharded.hip.h"

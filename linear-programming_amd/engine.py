@@ -108,6 +108,7 @@ def library():
         "lpamd_group_objective_constant": (ctypes.c_int, [vp, P(ctypes.c_double)]),
         "lpamd_group_pivot_count": (ctypes.c_int, [vp, P(i64)]),
         "lpamd_group_trace": (ctypes.c_int, [vp, vp, vp, i64, P(i64)]),
+        "lpamd_ratio_test_noalloc": (ctypes.c_int, [vp, vp, i64, vp, vp, vp]),
         "lpamd_rev_create": (ctypes.c_int, [P(vp), i64, i64, vp]),
         "lpamd_rev_destroy": (ctypes.c_int, [vp]),
         "lpamd_rev_upload": (ctypes.c_int, [vp, vp, i64, vp, vp, i32]),
@@ -143,6 +144,13 @@ def fold_candidates(strategy, records, world, N):
     _ck(library().lpamd_fold_candidates(int(strategy), rec.ctypes.data, int(world), int(N), ctypes.byref(e), ctypes.byref(r),
                                         ctypes.byref(owner), ctypes.byref(res), win.ctypes.data))
     return e.value, r.value, owner.value, res.value, win
+
+
+def ratio_test_noalloc(col_ptr, rhs_ptr, m, row_out_ptr, ratio_out_ptr=None, stream=None):
+    """lpamd_ratio_test_noalloc on raw device pointers (ints); asynchronous on `stream`."""
+    _ck(library().lpamd_ratio_test_noalloc(ctypes.c_void_p(col_ptr), ctypes.c_void_p(rhs_ptr), int(m), ctypes.c_void_p(row_out_ptr),
+                                           ctypes.c_void_p(ratio_out_ptr) if ratio_out_ptr else None,
+                                           ctypes.c_void_p(stream) if stream else None))
 
 
 class TableauEngine:
