@@ -137,6 +137,12 @@ def main():
         # Not started by a launcher: start one rank per GPU as a child, before anything here touches a GPU.
         sys.exit(subprocess.call(launch_command(args.gpus, sys.argv[1:], free_port())))
 
+    # The one JSON line must be the only thing on stdout, but libraries print there too (RCCL writes a version
+    # banner when a communicator is created): keep the real stdout aside and send everything else to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -266,7 +272,8 @@ def main():
         except Exception as ex:   # the baseline must never cost the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "pivots/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (ex,)}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if group is not None:
         group.close()
     if use_dist:

@@ -746,7 +746,8 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // partial reductions: 256 columns / 256 rows per workgroup, strided beyond kMaxPartials workgroups
   e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 1 + kPartialThreads - 1) / kPartialThreads));
   e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
-  e->n_row_blocks = (int32_t)std::min<int64_t>(64, std::max<int64_t>(1, (m + 2047) / 2048));
+  e->n_row_blocks = (int32_t)std::min<int64_t>(256, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));   // one row per thread up to 65536 rows
+  if (const char* env = getenv("LPAMD_ROW_BLOCKS")) e->n_row_blocks = std::max(1, std::min(1024, atoi(env)));
   HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
   HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * e->chain_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));

@@ -699,12 +699,26 @@ __device__ __forceinline__ void chain_account(ChainStep* steps, const PassInfo& 
 
 // v as steps 0..j-1 leave it.  rs points at row'_0 of the entry's column (stride rstride between steps),
 // cs at col'_0 of its row (stride lda).  A step whose row' entry is exactly 0 leaves the column alone.
+// The operands of several steps are fetched before the first of them is applied: the steps depend on each
+// other, their loads do not, and one round trip to L2 per step is what these short kernels would otherwise cost.
+template <int kBatch>
+__device__ __forceinline__ double chain_apply_batch(double v, int s, const double* __restrict__ cs, int64_t lda,
+                                                    const double* __restrict__ rs, int64_t rstride) {
+  double r[kBatch], c[kBatch];
+#pragma unroll
+  for (int q = 0; q < kBatch; q++) { r[q] = rs[(s + q) * rstride]; c[q] = cs[(s + q) * lda]; }
+#pragma unroll
+  for (int q = 0; q < kBatch; q++)
+    if (r[q] != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(c[q], r[q])));
+  return v;
+}
 __device__ __forceinline__ double chain_apply(double v, int j, const double* __restrict__ cs, int64_t lda,
                                               const double* __restrict__ rs, int64_t rstride) {
-  for (int s = 0; s < j; s++) {
-    const double r = rs[s * rstride];
-    if (r != 0.0) v = flushz(__dadd_rn(v, __dmul_rn(cs[s * lda], r)));
-  }
+  int s = 0;
+  for (; s + 8 <= j; s += 8) v = chain_apply_batch<8>(v, s, cs, lda, rs, rstride);
+  if (s + 4 <= j) { v = chain_apply_batch<4>(v, s, cs, lda, rs, rstride); s += 4; }
+  if (s + 2 <= j) { v = chain_apply_batch<2>(v, s, cs, lda, rs, rstride); s += 2; }
+  if (s < j) v = chain_apply_batch<1>(v, s, cs, lda, rs, rstride);
   return v;
 }
 

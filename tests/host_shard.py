@@ -1,5 +1,5 @@
 """TEST DOUBLE: a column shard that lives in host memory (numpy), with the same
-interface as linear-programming_amd.sharded.EngineShard.  It lets the
+interface as sharded_harness.EngineShard.  It lets the
 multi-rank driver (ShardedSolver) run under the gloo backend on a machine
 without GPUs.  Arithmetic follows the oracle's rules (separately rounded
 multiply/add, flush of |x| < 1e-6f, float-typed predicates)."""

@@ -1,9 +1,13 @@
-"""Column-sharded pivot loop driven from Python over the step-wise C ABI, one process per GPU.
+"""TEST HARNESS: the column-sharded pivot loop driven from Python over the step-wise C ABI, one
+process per rank.
 
-The library runs the same loops itself behind lpamd_group_* (RCCL inside, no Python in the loop;
-that is what bench.py and the `solver` binary use).  This module is the caller-driven form: it shows
-how a host that owns the collectives drives the engines step by step, and it is the harness of
-the multi-process CPU tests, where a host stand-in takes the place of the GPU shard.
+The product runs these loops itself behind lpamd_group_* (RCCL inside, no Python in the loop; that is
+what bench.py and the `solver` binary use).  This module is the caller-driven form of the same
+protocols: it shows how a host that owns the collectives drives the engines step by step
+(lpamd_local_candidate, lpamd_lookahead_*, lpamd_chain_step, ...), and it is what the multi-process
+CPU tests run over gloo with a host stand-in in place of the GPU shard.  Its feasibility phase
+restates reference lp_simplex_tableau.cc:64-171 in numpy as a checker of the library's own
+(lpamd_phase1, lpamd_group_solve).
 
 Each rank owns the tableau columns whose ordinal is congruent to its rank
 (round-robin deal, so the dense columns stay balanced while the basis drifts)
@@ -31,7 +35,9 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import engine as _eng
+import importlib
+
+_eng = importlib.import_module("linear-programming_amd.engine")
 
 _EPS32 = np.float32(1e-6)
 

@@ -83,10 +83,10 @@ def _sample_columns(rng, n, N, trace, k):
 
 
 def test_m32768_n65536_two_chained_passes_bit_exact(lpamd, monkeypatch):
-    """The configuration of the headline benchmark at its own size: 16 pivots (two full passes of the
+    """The configuration of the headline benchmark at its own size: 32 pivots (two full passes of the
     default chained loop) against the oracle (reference lp_simplex_tableau.cc:10-52, 188-227), every
-    entry of the 25.8 GB tableau included; then the same 16 pivots with one pass per pivot."""
-    m, n, seed, k = 32768, 65536, 1, 16
+    entry of the 25.8 GB tableau included; then the same 32 pivots with one pass per pivot."""
+    m, n, seed, k = 32768, 65536, 1, 32
     N = n + m
     eng = lpamd.TableauEngine(m, N)          # default knobs
     eng.fill_synthetic(n, seed)
@@ -189,7 +189,7 @@ def test_m32768_n65536_as_eight_shards(lpamd):
     the library's own loop (lpamd_group_*), here on one GPU with the in-process exchange: two full
     chained passes; every shard walks the single-engine pivots, the RHS replicas stay bit-identical, and
     sampled columns, objective row and basis flags equal the single-engine loop's."""
-    m, n, seed, k = 32768, 65536, 1, 16
+    m, n, seed, k = 32768, 65536, 1, 32
     N = n + m
     g = lpamd.ShardGroup(m, N, 8, devices=[0] * 8, local_exchange=True)
     assert g.chain() >= 8

@@ -27,7 +27,7 @@ def _free_port():
 def _worker(rank, world, port, case, strategy_name, out_dir, exchange):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from host_shard import HostShard
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     if case[0] == "synthetic":
@@ -104,7 +104,7 @@ def _check_loop(tmp_path, case, strategy, exchange, world):
 def _solve_worker(rank, world, port, name, strategy_name, out_dir, exchange):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from host_shard import HostShard
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     tab, _ = lo.from_text(case_text(name))

@@ -90,7 +90,7 @@ def assemble(shards, m, N):
 @pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
 @pytest.mark.parametrize("world", [2, 3])
 def test_two_shards_one_gpu_synthetic(lpamd, strategy, world, hostfree):
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -122,7 +122,7 @@ def test_two_shards_one_gpu_synthetic(lpamd, strategy, world, hostfree):
 
 def test_two_shards_uploaded_lp_without_phase1(lpamd):
     """test12 needs no phase 1: upload the same host matrix to both shards."""
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     tab, dt = lo.from_text(case_text("test12"))
@@ -140,7 +140,7 @@ def test_two_shards_uploaded_lp_without_phase1(lpamd):
 
 
 def test_single_rank_sharded_solver_equals_device_loop(lpamd):
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     m, n, seed = 300, 500, 4
@@ -171,7 +171,7 @@ def test_rccl_collectives_single_rank(lpamd, exchange):
     of the sharded loop run for real on the GPU."""
     import socket
     import torch.distributed as dist
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -230,7 +230,7 @@ class ThreadComm:
 
 def solve_in_threads(lpamd, tab, world, strategy, exchange):
     import threading
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     shared = {"barrier": threading.Barrier(world), "slots": [None] * world}
@@ -303,7 +303,7 @@ def test_rccl_single_rank_solve_with_feasibility_phase(lpamd, exchange):
     import torch.distributed as dist
     from cases import case_golden
     from oracle import lp_frontend as fe
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -334,7 +334,7 @@ def test_lookahead_exchange_overlaps_update_bit_exact(lpamd, monkeypatch, world,
     over the shard (lpamd_chain_step): trace, tableau and RHS replicas must equal the single-engine
     one-pivot-per-pass device loop bit for bit, across two budgeted legs that end inside a chain."""
     import threading
-    sharded = importlib.import_module("linear-programming_amd.sharded")
+    import sharded_harness as sharded
     eng = importlib.import_module("linear-programming_amd.engine")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
