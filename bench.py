@@ -209,6 +209,7 @@ def main():
     sync_all()
     el = time.perf_counter() - t0
     upd_ms, passes, pivots, streamed_cols, touched_cols = eng.profile_totals()
+    priced, evaluated = eng.pricing_stats()
     eng.set_profiling(False)
     assert done == K and res == lp.LIMIT, "timed region ended early: result %d after %d pivots" % (res, done)
     assert pivots == K or passes == 0, "device totals (%d pivots) disagree with the %d pivots timed" % (pivots, K)
@@ -254,6 +255,8 @@ def main():
         "update_GBps_aggregate": round(achieved * world, 1),
         "pivots_per_pass": round(pivots / max(passes, 1), 3),
         "algorithmic_GBps": round(algo_bytes / secs / 1e9, 1) if passes else 0.0,
+        **({"max_reduction_pricing": {"pricings": priced, "columns_evaluated_exactly": evaluated,
+                                      "note": "since the engine was created (the first pricing evaluates every candidate column)"}} if priced else {}),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": round(ratio * per_launch) if ratio else None,

@@ -139,6 +139,10 @@ int lpamd_pass_stats(lpamd_engine* eng, int32_t* pivots, int64_t* streamed_colum
  * (the algorithmic 16*m bytes per column and pivot).  Any pointer may be NULL. */
 int lpamd_profile_totals(lpamd_engine* eng, double* total_ms, int64_t* passes, int64_t* pivots, int64_t* streamed_columns,
                          int64_t* touched_columns);
+/* MAX_REDUCTION pricing from bounds (long columns, one GPU): pricings done since the engine was created and the
+ * candidate columns they had to evaluate exactly, over all rows (the reference evaluates every candidate column
+ * every time, lp_simplex_tableau.cc:275-309). */
+int lpamd_pricing_stats(lpamd_engine* eng, int64_t* pricings, int64_t* columns_evaluated);
 /* Pivots one pass of the device loop (lpamd_run_pivots / lpamd_solve) applies at most for `strategy`. */
 int lpamd_loop_depth(const lpamd_engine* eng, int32_t strategy, int32_t* depth);
 

@@ -3,6 +3,7 @@
 // and keeps the pivot loop on the device (the host only reads the 64-byte
 // PivotState back once per batch of pivots).
 #include "lpamd_kernels.hip.h"
+#include "lpamd_prbound_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -75,6 +76,21 @@ struct lpamd_engine {
   int64_t rstride = 0;
   ChainStep* steps = nullptr;   // [kMaxChain]
   double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
+  // MAX_REDUCTION pricing from bounds (lpamd_prbound_kernels.hip.h): lets those pivots chain as well
+  bool pr_bounds = false;
+  PrbInfo* prb_info = nullptr;
+  double* prb_c = nullptr;       // [kMaxChain * kPrbRows] col'_s at the rows of the bound
+  double* prb_v = nullptr;       // [3 * kMaxPartials] partials: smallest right-hand sides, largest bounds
+  int64_t* prb_i = nullptr;      // [3 * kMaxPartials]
+  PrbRows* prb_rowbuf = nullptr; // rows that met the threshold of the row selection
+  double* prb_ep_v = nullptr;    // [kPrbSliced * kPrbSlices] ratio partials of a short list evaluated in slices
+  int64_t* prb_ep_i = nullptr;
+  int32_t prb_rows = kPrbRows;   // rows the bounds are taken from
+  double* prb_ub = nullptr;      // [ncl] bound per candidate column
+  uint8_t* prb_ucand = nullptr;  // [ncl] candidate flags
+  int32_t* prb_elist = nullptr;  // [ncl] columns to evaluate exactly
+  double* prb_escore = nullptr;  // [ncl] exact score ...
+  int64_t* prb_erow = nullptr;   // [ncl] ... and row of the evaluated columns
   PassInfo* pass = nullptr;     // what the pass kernel has to do (k_chain_list)
   int32_t* list_full = nullptr; // [ncl] columns every step of the chain touches ...
   int32_t* list_part = nullptr; // [ncl] ... and columns some steps leave alone
@@ -459,15 +475,69 @@ int enqueue_chain_step(lpamd_engine* e, int j, const Candidate* xcand, double* x
     hipLaunchKernelGGL(k_chain_ratio<false>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j,
                        e->chain_depth, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->rhs_next, colv, rv, ri, xcand);
   LP_TRY(check_launch("k_chain_ratio"));
-  hipLaunchKernelGGL(k_chain_finalize, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st,
-                     e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, colv, e->obj,
-                     e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i);
+  hipLaunchKernelGGL((k_chain_finalize<true, false>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh,
+                     e->st, e->steps, j, rv, ri, e->n_ratio_part, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, colv, xcand,
+                     e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i);
   LP_TRY(check_launch("k_chain_finalize"));
   e->price_partials_fresh = true;
   return LPAMD_OK;
 }
 
 int enqueue_chain_update(lpamd_engine* e);
+
+// MAX_REDUCTION pricing of step j of a pass from bounds (six small launches, no pass over the tableau): the
+// candidate record (column, row, score) lands in `cand`.
+int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand) {
+  const int n_seg = (int)std::min<int64_t>(kPrbSegments, e->sh.m);   // segments of the rows whose minima give the threshold
+  double* sm_v = e->prb_v;
+  double* pv = e->prb_v + kMaxPartials;
+  int64_t* pi = e->prb_i + kMaxPartials;
+  int64_t* pf = e->prb_i + 2 * kMaxPartials;
+  double* rv = e->part_v + kMaxPartials;
+  int64_t* ri = e->part_i + kMaxPartials;
+  hipLaunchKernelGGL(k_prb_small_rows, dim3(n_seg), dim3(kWave), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->rhs_next, sm_v,
+                     e->prb_rowbuf);
+  LP_TRY(check_launch("k_prb_small_rows"));
+  hipLaunchKernelGGL(k_prb_collect_rows, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->rhs_next,
+                     sm_v, n_seg, e->prb_rows, e->prb_rowbuf);
+  LP_TRY(check_launch("k_prb_collect_rows"));
+  hipLaunchKernelGGL(k_prb_pick_rows, dim3(1), dim3(kWave), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next, e->colp,
+                     e->prb_rowbuf, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
+  LP_TRY(check_launch("k_prb_pick_rows"));
+  hipLaunchKernelGGL(k_prb_bounds, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
+                     e->rowp, e->rstride, e->prb_info, e->prb_c, e->prb_ub, e->prb_ucand, pv, pi, pf);
+  LP_TRY(check_launch("k_prb_bounds"));
+  hipLaunchKernelGGL(k_prb_first, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->colp, e->rowp,
+                     e->rstride, e->rhs_next, pv, pi, pf, e->n_price_part, e->prb_info, rv, ri);
+  LP_TRY(check_launch("k_prb_first"));
+  hipLaunchKernelGGL(k_prb_list, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->sh, e->st, e->steps, j, e->obj, rv, ri,
+                     e->n_ratio_part, e->prb_ub, e->prb_ucand, e->prb_info, e->prb_elist, e->prb_escore, e->prb_erow);
+  LP_TRY(check_launch("k_prb_list"));
+  const int n_slices = std::min(e->n_ratio_part, kPrbSlices);
+  hipLaunchKernelGGL(k_prb_eval, dim3(2048), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj,
+                     e->colp, e->rowp, e->rstride, e->rhs_next, e->prb_info, e->prb_elist, e->prb_escore, e->prb_erow, n_slices, e->prb_ep_v,
+                     e->prb_ep_i);
+  LP_TRY(check_launch("k_prb_eval"));
+  hipLaunchKernelGGL(k_prb_pick, dim3(1), dim3(kPartialThreads), 0, e->stream, e->sh, e->st, e->steps, j, e->obj, e->prb_info, e->prb_elist,
+                     e->prb_escore, e->prb_erow, n_slices, e->prb_ep_v, e->prb_ep_i, cand);
+  return check_launch("k_prb_pick");
+}
+
+// One pass of MAX_REDUCTION pivots: every step is priced from bounds and set up on entries rebuilt through the
+// steps before it; the pass kernel then applies the chain.
+int enqueue_prb_pass(lpamd_engine* e) {
+  LP_TRY(enqueue_prb_pricing(e, 0, e->cand));
+  LP_TRY(enqueue_finalize(e, false, e->cand, nullptr, -1));
+  for (int j = 1; j < e->chain_depth; j++) {
+    LP_TRY(enqueue_prb_pricing(e, j, e->cand));
+    hipLaunchKernelGGL((k_chain_finalize<false, true>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T,
+                       e->sh, e->st, e->steps, j, nullptr, nullptr, 0, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, nullptr,
+                       e->cand, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i);
+    LP_TRY(check_launch("k_chain_finalize"));
+  }
+  e->price_partials_fresh = false;
+  return enqueue_chain_update(e);
+}
 
 // The further pivots of a pass and the pass itself, for the pivot that k_pivot_finalize has just set up.
 int enqueue_chain_tail(lpamd_engine* e, int depth) {
@@ -544,6 +614,7 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
     LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
     return enqueue_finalize_update(e, true, e->cand, nullptr, -1);
   }
+  if (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds) return enqueue_prb_pass(e);
   LP_TRY(enqueue_pricing(e, strategy, e->cand));
   return enqueue_finalize_update(e, false, e->cand, nullptr, -1, strategy == LPAMD_MAX_REDUCTION);
 }
@@ -570,7 +641,7 @@ int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   // With a budget the whole run is enqueued at once (kernels turn into no-ops
   // once the status leaves RUNNING); without one the batch grows geometrically.
   int64_t batch = budget >= 0 ? 1024 : 8;
-  const int64_t depth = strategy == LPAMD_MAX_COST ? e->chain_depth : 1;   // pivots an iteration may apply
+  const int64_t depth = (strategy == LPAMD_MAX_COST || (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds)) ? e->chain_depth : 1;   // pivots an iteration may apply
   e->loop_depth = (int32_t)depth;
   for (;;) {
     int64_t todo = batch;
@@ -729,6 +800,26 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
   HIP_TRY(hipMalloc(&e->colv, sizeof(double) * e->sh.lda));
+  // MAX_REDUCTION prices from bounds wherever pivots chain (world == 1; column shards keep the in-order exchange)
+  e->pr_bounds = e->chain_depth > 1 && world == 1;
+  if (const char* env = getenv("LPAMD_PR_BOUNDS")) e->pr_bounds = e->pr_bounds && atoi(env) != 0;
+  if (e->pr_bounds) {
+    HIP_TRY(hipMalloc(&e->prb_info, sizeof(PrbInfo)));
+    HIP_TRY(hipMemsetAsync(e->prb_info, 0, sizeof(PrbInfo), e->stream));
+    HIP_TRY(hipMalloc(&e->prb_c, sizeof(double) * kMaxChain * kPrbRows));
+    HIP_TRY(hipMalloc(&e->prb_v, sizeof(double) * 3 * kMaxPartials));
+    HIP_TRY(hipMalloc(&e->prb_i, sizeof(int64_t) * 3 * kMaxPartials));
+    HIP_TRY(hipMalloc(&e->prb_rowbuf, sizeof(PrbRows)));
+    HIP_TRY(hipMemsetAsync(e->prb_rowbuf, 0, sizeof(PrbRows), e->stream));
+    HIP_TRY(hipMalloc(&e->prb_ep_v, sizeof(double) * kPrbSliced * kPrbSlices));
+    HIP_TRY(hipMalloc(&e->prb_ep_i, sizeof(int64_t) * kPrbSliced * kPrbSlices));
+    if (const char* env = getenv("LPAMD_PRB_ROWS")) e->prb_rows = std::max(1, std::min(kPrbRows, atoi(env)));
+    HIP_TRY(hipMalloc(&e->prb_ub, sizeof(double) * e->ncl));
+    HIP_TRY(hipMalloc(&e->prb_ucand, e->ncl));
+    HIP_TRY(hipMalloc(&e->prb_elist, sizeof(int32_t) * e->ncl));
+    HIP_TRY(hipMalloc(&e->prb_escore, sizeof(double) * e->ncl));
+    HIP_TRY(hipMalloc(&e->prb_erow, sizeof(int64_t) * e->ncl));
+  }
   HIP_TRY(hipMalloc(&e->pass, sizeof(PassInfo)));
   HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
   if (e->chain_depth > 1) {
@@ -762,7 +853,8 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part};
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part,
+                  e->prb_info, e->prb_c, e->prb_v, e->prb_i, e->prb_rowbuf, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1241,9 +1333,19 @@ int lpamd_profile_totals(lpamd_engine* e, double* total_ms, int64_t* passes, int
   return LPAMD_OK;
 }
 
+int lpamd_pricing_stats(lpamd_engine* e, int64_t* pricings, int64_t* columns_evaluated) {
+  CHECK_ENGINE(e);
+  PrbInfo pi;
+  std::memset(&pi, 0, sizeof(pi));
+  if (e->prb_info) LP_TRY(read_local(e, e->prb_info, &pi, sizeof(pi)));
+  if (pricings) *pricings = pi.priced;
+  if (columns_evaluated) *columns_evaluated = pi.priced + pi.listed;   // the column with the largest bound is always evaluated
+  return LPAMD_OK;
+}
+
 int lpamd_loop_depth(const lpamd_engine* e, int32_t strategy, int32_t* depth) {
   if (!e || !depth) return set_err(LPAMD_E_ARG, "loop_depth: null argument");
-  *depth = (strategy == LPAMD_MAX_COST && !e->two_launch) ? e->chain_depth : 1;
+  *depth = ((strategy == LPAMD_MAX_COST && !e->two_launch) || (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds)) ? e->chain_depth : 1;
   return LPAMD_OK;
 }
 

@@ -778,10 +778,15 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
 // fold, scalars, col'_j, the right-hand side after the step, the pivot row gathered with steps
 // 0..j-1 applied on the fly, row'_j, the objective row, the pricing partials of the iteration after
 // this step.  PivotState keeps describing pivot 0 until the pass kernel has used it.
+// kFindRow: the row comes from the ratio-test partials (MAX_COST); otherwise with the candidate
+// record `xcand` (MAX_REDUCTION prices column and row together).  kRebuild: the entering column is
+// a local column and is rebuilt here through the steps so far; otherwise it is given in `colv`.
+template <bool kFindRow, bool kRebuild>
 __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
     const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
     double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, double* __restrict__ rhsv, const double* __restrict__ colv,
+    const Candidate* __restrict__ xcand,
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
     int64_t* __restrict__ trace, int64_t trace_cap,
     double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
@@ -791,12 +796,24 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   if (j > 1 && !steps[j - 1].done) return;
   const int64_t e2 = steps[j].e;
   if (e2 < 0) return;
-  double best;
   int64_t r2;
-  fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2, s_v, s_i);
+  if (kFindRow) {
+    double best;
+    fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2, s_v, s_i);
+  } else {
+    r2 = xcand->gcol == e2 ? xcand->row : -1;
+  }
   if (r2 < 0) return;   // unbounded after step j-1: found again, and reported, by the next iteration
+  auto local_id = [&](int64_t g) -> int {
+    if (g < 0 || g == sh.N) return -1;
+    const int64_t o = ordinal_of(g, sh.N);
+    return (o % sh.world == sh.rank) ? (int)(o / sh.world) : -1;
+  };
+  const int l_e2 = local_id(e2);
+  if (kRebuild && l_e2 < 0) return;   // not reachable: a rebuilt column is a local one
+  const double* __restrict__ ecol = kRebuild ? T.col(l_e2) : colv;
   const double ce2 = steps[j].ce;
-  const double a2 = colv[r2];
+  const double a2 = kRebuild ? chain_apply(ecol[r2], j, colp + r2, sh.lda, rowp + l_e2, rstride) : colv[r2];
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
   if ((int)blockIdx.x < n_row_blocks) {
@@ -805,7 +822,8 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     double* __restrict__ rhs_now = rhsv + (int64_t)j * sh.lda;
     const double rp_rhs = __dmul_rn(rhs_prev[r2], f2);   // row'_j of the right-hand-side column
     for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
-      const double cpi = (i == r2) ? __dadd_rn(1.0, a2) : colv[i];
+      const double ci = kRebuild ? chain_apply(ecol[i], j, colp + i, sh.lda, rowp + l_e2, rstride) : colv[i];
+      const double cpi = (i == r2) ? __dadd_rn(1.0, a2) : ci;
       cj[i] = cpi;
       rhs_now[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs_prev[i], __dmul_rn(cpi, rp_rhs))) : rhs_prev[i];
     }
@@ -813,17 +831,12 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   }
   const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
   const int ncl = sh.nloc + 1;
-  auto local_id = [&](int64_t g) -> int {
-    if (g < 0 || g == sh.N) return -1;
-    const int64_t o = ordinal_of(g, sh.N);
-    return (o % sh.world == sh.rank) ? (int)(o / sh.world) : -1;
-  };
   // the basic variable of row r2 after steps 0..j-1 (basis[] is flipped by the pass kernel)
   int64_t d2 = basis[r2];
   if (st->r == r2) d2 = st->e;
   for (int s = 1; s < j; s++)
     if (steps[s].r == r2) d2 = steps[s].e;
-  const int l_e2 = local_id(e2), l_d2 = local_id(d2);
+  const int l_d2 = local_id(d2);
   const double* __restrict__ c_r = colp + r2;       // col'_s[r2] at c_r[s * lda]
   double nbv = -DBL_MAX;
   int64_t nbi = -1;

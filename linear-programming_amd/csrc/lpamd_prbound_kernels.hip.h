@@ -1,0 +1,454 @@
+// MAX_REDUCTION pricing without a pass over the tableau (reference lp_simplex_tableau.cc:235-374).
+//
+// The reference scores every candidate column j with c_j * min_i b_i / (-T_ij) over its eligible
+// rows and takes the largest score (lowest column on ties).  Done literally that is a read of the
+// whole tableau per pivot, after the update of the pivot before: one pass per pivot, no chains.
+// The same decision can be reached from far fewer entries:
+//   - for ANY set R of rows, u_j = c_j * min_{i in R, eligible} b_i / (-T_ij) is an upper bound of
+//     column j's score (a minimum over fewer rows; the rounded division and the rounded product with
+//     c_j > 0 are monotone, so the bound holds for the computed values, not just the exact ones);
+//   - the exact score s1 of ONE column is a lower bound of the winning score;
+//   - so every column with u_j < s1 is out, whatever its exact score is.
+// R = the rows with the smallest right-hand side: that is where the minimum ratio of almost every
+// column sits, so the bounds are tight and hardly any column survives: the column with the largest
+// bound is evaluated exactly (s1), then the few columns with u_j >= s1, and the fold over those
+// exact results applies the reference's rule.  Cost per pivot: |R| entries per candidate column
+// instead of m.  Every entry is taken as the pivots set up so far will leave it (chain_apply), so
+// these pivots chain like the MAX_COST ones: one pass over the tableau per chain.
+// When no bound helps (first iteration of a degenerate start, columns without an eligible row in R:
+// u_j = +inf) the survivors are simply all candidates and the scheme degrades to the full evaluation.
+#pragma once
+
+namespace lpamd {
+
+constexpr int kPrbRows = 32;
+constexpr int kPrbRecent = 8;    // rows of the latest pivots that are always part of R
+
+struct PrbInfo {
+  int32_t n_rows;          // rows of R in use
+  int32_t n_list;          // columns to evaluate exactly besides l1
+  int32_t l1;              // local column with the largest bound (-1: no candidate column)
+  int32_t first;           // lowest candidate column (the reference reports it when no candidate has a row)
+  double s1;               // exact score of l1 (-DBL_MAX: it has no eligible row)
+  int32_t rows[kPrbRows];
+  double b[kPrbRows];      // right-hand side at those rows, as the pivots set up so far leave it
+  int64_t priced, listed;  // running totals: pricings done, columns they evaluated exactly besides l1
+};
+
+// true while step j of the pass may still be set up (the same tests k_chain_ratio makes)
+__device__ __forceinline__ bool prb_step_alive(const PivotState* st, const ChainStep* steps, int j) {
+  if (st->status != ST_RUNNING) return false;
+  if (j > 1 && !steps[j - 1].done) return false;   // the chain ended before this step
+  if (j >= 1 && st->iter >= st->max_iter) return false;   // the budget ends with step j-1 (step 0 reports LIMIT itself)
+  return true;
+}
+
+// right-hand side as steps 0..j-1 leave it
+__device__ __forceinline__ const double* prb_rhs(const Tab& T, const Shape& sh, const double* rhsv, int j) {
+  return j == 0 ? T.col(sh.nloc) : rhsv + (int64_t)(j - 1) * sh.lda;
+}
+
+// The rows of R.  Exactly the rows with the smallest right-hand side matter (a row of rank 3 that is missed
+// costs a full evaluation of thousands of columns when it holds the minimum of the column with the largest
+// bound), so the selection is exact: (a) the minimum of every segment of the rows; (b) the
+// kPrbRows-th smallest of those minima is a threshold that at least kPrbRows rows meet, and hardly more:
+// all rows that meet it are collected; (c) one wavefront takes the smallest of the collected rows.
+// With (a) over 128 segments of the rows the threshold is met by about 40 rows.
+constexpr int kPrbCollect = 512;   // rows (c) can hold; more than that met the threshold only for short columns
+
+struct PrbRows {
+  int32_t n_collected;
+  int32_t pad;
+  int32_t row[kPrbCollect];
+  double b[kPrbCollect];
+};
+
+// 1a. smallest right-hand side of each of gridDim.x segments of the rows (one wavefront per segment)
+constexpr int kPrbSegments = 128;
+__global__ __launch_bounds__(kWave) void k_prb_small_rows(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ rhsv, double* __restrict__ sm_v, PrbRows* __restrict__ rows) {
+  if (!prb_step_alive(st, steps, j)) return;
+  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
+  const int64_t seg = (sh.m + gridDim.x - 1) / gridDim.x;
+  const int64_t i1 = min((int64_t)(blockIdx.x + 1) * seg, sh.m);
+  double bv = DBL_MAX;
+  for (int64_t i = (int64_t)blockIdx.x * seg + threadIdx.x; i < i1; i += kWave) bv = fmin(bv, rhs[i]);
+#pragma unroll
+  for (int off = kWave / 2; off > 0; off >>= 1) bv = fmin(bv, __shfl_xor(bv, off, kWave));
+  if (threadIdx.x == 0) sm_v[blockIdx.x] = bv;
+  if (blockIdx.x == 0 && threadIdx.x == 0) rows->n_collected = 0;
+}
+
+// 1b. every workgroup ranks the minima (n <= kPrbSegments of them, in LDS) to find the threshold, the `want`-th
+// smallest, and appends its rows that meet it.  (Finding the threshold once, in the workgroup of 1a that
+// finishes last, needs a device-wide fence, which costs more on this chip than ranking the values again.)
+__global__ __launch_bounds__(kPartialThreads) void k_prb_collect_rows(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ rhsv, const double* __restrict__ sm_v, int n, int want, PrbRows* __restrict__ rows) {
+  __shared__ double s_all[kPrbSegments];
+  __shared__ double s_tau;
+  if (!prb_step_alive(st, steps, j)) return;
+  for (int k = threadIdx.x; k < n; k += kPartialThreads) s_all[k] = sm_v[k];
+  if (threadIdx.x == 0) s_tau = DBL_MAX;          // fewer minima than rows wanted: every row qualifies
+  __syncthreads();
+  for (int k = threadIdx.x; k < n; k += kPartialThreads) {
+    const double mine = s_all[k];
+    int rank = 0;
+    for (int q = 0; q < n; q++) rank += (s_all[q] < mine || (s_all[q] == mine && q < k)) ? 1 : 0;
+    if (rank == want - 1) s_tau = mine;
+  }
+  __syncthreads();
+  const double tau = s_tau;
+  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
+  for (int64_t i0 = (int64_t)blockIdx.x * kPartialThreads; i0 < sh.m; i0 += (int64_t)gridDim.x * kPartialThreads) {
+    const int64_t i = i0 + threadIdx.x;
+    const double b = i < sh.m ? rhs[i] : 0.0;
+    const bool take = i < sh.m && b <= tau;
+    const unsigned long long mask = __ballot(take);
+    if (mask) {
+      const int lane = threadIdx.x & (kWave - 1);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&rows->n_collected, __popcll(mask));
+      base = __shfl(base, 0, kWave);
+      const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
+      if (take && k < kPrbCollect) { rows->row[k] = (int32_t)i; rows->b[k] = b; }
+    }
+  }
+}
+
+// true on every lane whose `row` equals one of the rows the first n lanes hold in `held`
+__device__ __forceinline__ bool __any_dup(int64_t row, int64_t held, int n, int lane) {
+  bool dup = false;
+  for (int q = 0; q < n; q++) dup = dup || __shfl(held, q, kWave) == row;
+  (void)lane;
+  return dup;
+}
+
+// 1c. R: the rows of the latest pivots, then the smallest of the collected rows (lowest row on equal
+// right-hand sides), with the right-hand side and the col' entries of the steps so far at those rows.
+__global__ __launch_bounds__(kWave) void k_prb_pick_rows(
+    Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
+    const double* __restrict__ rhsv, const double* __restrict__ colp, const PrbRows* __restrict__ rows, int max_rows,
+    const int64_t* __restrict__ trace, int64_t trace_cap, PrbInfo* __restrict__ info, double* __restrict__ prb_c) {
+  if (st->status != ST_RUNNING) return;
+  const int lane = threadIdx.x;
+  // the step records of the pass before are cleared even when the budget ends with step 0 (k_chain_list counts them)
+  if (j == 1 && lane == 0) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
+  if (j == 0 && st->iter >= st->max_iter) { if (lane == 0) st->status = ST_LIMIT; return; }   // as k_pr_fold does
+  if (!prb_step_alive(st, steps, j)) return;
+  constexpr int kPer = kPrbCollect / kWave;
+  const int n_coll = min(rows->n_collected, kPrbCollect);
+  double v[kPer];
+  int64_t r[kPer];
+#pragma unroll
+  for (int q = 0; q < kPer; q++) {
+    const int k = lane + q * kWave;
+    v[q] = k < n_coll ? rows->b[k] : DBL_MAX;
+    r[q] = k < n_coll ? rows->row[k] : -1;
+  }
+  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
+  // The rows of the latest pivots come first: a pivot scales its row by 1 / |pivot element|, and a row of
+  // large entries holds the minimum ratio of many columns without having a small right-hand side.
+  int n_rows = 0;
+  int64_t mine = -1;       // lane k keeps row k of R
+  const int64_t it = st->iter;
+  const int64_t tq = it - 1 - lane;
+  const int64_t recent = (lane < kPrbRecent && tq >= 0 && tq < trace_cap) ? trace[2 * tq + 1] : -1;   // all loads at once
+  for (int q = 0; q < kPrbRecent && n_rows < max_rows; q++) {
+    const int64_t row = __shfl(recent, q, kWave);
+    if (row < 0) break;
+    const bool dup = __any(lane < n_rows && mine == row);
+    if (dup) continue;
+    if (lane == n_rows) mine = row;
+    n_rows++;
+  }
+  // then the rows with the smallest right-hand side; the selection itself touches no memory
+  if (n_coll <= kWave) {
+    // the usual case, one collected row per lane: a row's rank among the rows that are not pivot rows already
+    const double mv = v[0];
+    const int64_t mr = r[0];
+    const bool fresh = !__any_dup(mr, mine, n_rows, lane) && mr >= 0;
+    int rank = 0;
+    for (int q = 0; q < n_coll; q++) {
+      const double ov = __shfl(mv, q, kWave);
+      const int64_t orow = __shfl(mr, q, kWave);
+      const bool ofresh = __shfl((int)fresh, q, kWave) != 0;
+      rank += (ofresh && (ov < mv || (ov == mv && orow < mr))) ? 1 : 0;
+    }
+    const bool take = fresh && rank < max_rows - n_rows;
+    const unsigned long long mask = __ballot(take);
+    const int pos = n_rows + __popcll(mask & ((1ull << lane) - 1ull));
+    // hand row `mr` of a taking lane to lane `pos`
+    for (int q = 0; q < kWave; q++) {
+      const bool tq = (mask >> q) & 1ull;
+      if (!tq) continue;
+      const int pq = n_rows + __popcll(mask & ((1ull << q) - 1ull));
+      const int64_t rq = __shfl(mr, q, kWave);
+      if (lane == pq) mine = rq;
+    }
+    (void)pos;
+    n_rows += __popcll(mask);
+  } else {
+    while (n_rows < max_rows) {
+      double bv = DBL_MAX;
+      int64_t bi = -1;
+#pragma unroll
+      for (int q = 0; q < kPer; q++) take_min(bv, bi, v[q], r[q]);
+      wave_arg<false>(bv, bi);
+      bi = __shfl(bi, 0, kWave);
+      if (bi < 0) break;
+#pragma unroll
+      for (int q = 0; q < kPer; q++)
+        if (r[q] == bi) r[q] = -1;     // rows are distinct: exactly one lane drops it
+      if (__any(lane < n_rows && mine == bi)) continue;   // already in R as a pivot row
+      if (lane == n_rows) mine = bi;
+      n_rows++;
+    }
+  }
+  __shared__ int64_t s_rows[kPrbRows];
+  if (lane < n_rows) { info->rows[lane] = (int32_t)mine; info->b[lane] = rhs[mine]; s_rows[lane] = mine; }
+  __syncthreads();
+  for (int t = lane; t < n_rows * j; t += kWave) {     // independent loads, a few per lane
+    const int k = t % n_rows, sidx = t / n_rows;
+    prb_c[sidx * kPrbRows + k] = colp[(int64_t)sidx * sh.lda + s_rows[k]];
+  }
+  if (lane == 0) { info->n_rows = n_rows; info->n_list = 0; info->l1 = -1; info->first = -1; info->s1 = -DBL_MAX; }
+}
+
+// basis flag of local column l after the pivots set up so far (the pass kernel flips is_basic[] later)
+__device__ __forceinline__ bool prb_basic(int l, int j, const uint8_t* is_basic, const PivotState* st, const ChainStep* steps) {
+  bool basic = is_basic[l] != 0;
+  if (j >= 1) {
+    if (l == st->l_e) basic = true; else if (l == st->l_d) basic = false;
+    for (int s = 1; s < j; s++) {
+      if (l == steps[s].l_in) basic = true; else if (l == steps[s].l_out) basic = false;
+    }
+  }
+  return basic;
+}
+
+// 2. bound u_l per candidate column from the rows of R; per-workgroup arg-max (lowest column on ties)
+// and lowest candidate column.
+__global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
+    const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info, const double* __restrict__ prb_c,
+    double* __restrict__ ub, uint8_t* __restrict__ ucand,
+    double* __restrict__ pv, int64_t* __restrict__ pi, int64_t* __restrict__ pfirst) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (!prb_step_alive(st, steps, j)) return;
+  const int n_rows = info->n_rows;
+  double bv = -DBL_MAX, fv = 0.0;
+  int64_t bi = -1, fi = -1;
+  for (int l = blockIdx.x * kPartialThreads + threadIdx.x; l < sh.nloc; l += gridDim.x * kPartialThreads) {
+    const double c = obj[l];
+    const bool cand = !prb_basic(l, j, is_basic, st, steps) && is_pos(c);
+    ucand[l] = cand ? 1 : 0;
+    if (!cand) continue;
+    if (fi < 0) fi = l;
+    const double* __restrict__ col = T.col(l);
+    double a[kPrbRows];
+#pragma unroll
+    for (int k = 0; k < kPrbRows; k++) a[k] = k < n_rows ? col[info->rows[k]] : 0.0;
+    for (int s = 0; s < j; s++) {
+      const double r = rowp[s * rstride + l];
+      if (r == 0.0) continue;                  // the update leaves the column alone in that step
+#pragma unroll
+      for (int k = 0; k < kPrbRows; k++) a[k] = flushz(__dadd_rn(a[k], __dmul_rn(prb_c[s * kPrbRows + k], r)));
+    }
+    double mn = DBL_MAX;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < kPrbRows; k++) {
+      if (k < n_rows && (float)a[k] <= -1e-6f) {
+        const double ratio = info->b[k] / (-a[k]);
+        if (!any || ratio < mn) mn = ratio;
+        any = true;
+      }
+    }
+    const double u = any ? __dmul_rn(c, mn) : DBL_MAX;   // no eligible row in R: no bound
+    ub[l] = u;
+    // The column evaluated first should have a TIGHT bound, so that its exact score rules the others out; a column
+    // without a bound is listed for evaluation anyway and would make a poor yardstick.
+    if (any && u > bv) { bv = u; bi = l; }
+  }
+  block_arg<true, kPartialThreads>(bv, bi, s_v, s_i);
+  fv = fi < 0 ? 0.0 : -(double)fi;
+  block_arg<true, kPartialThreads>(fv, fi, s_v, s_i);
+  if (threadIdx.x == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; pfirst[blockIdx.x] = fi; }
+}
+
+// exact minimum ratio of local column l over the rows [i0, m) strided by `stride`, as the steps so far leave it
+__device__ __forceinline__ void prb_column_min(const Tab& T, const Shape& sh, int l, int j, const double* __restrict__ colp,
+                                               const double* __restrict__ rowp, int64_t rstride, const double* __restrict__ rhs,
+                                               int64_t i0, int64_t stride, double& bv, int64_t& bi) {
+  const double* __restrict__ col = T.col(l);
+  for (int64_t i = i0; i < sh.m; i += stride) {
+    const double a = chain_apply(col[i], j, colp + i, sh.lda, rowp + l, rstride);
+    if ((float)a > -1e-6f) continue;                       // _IsNonNegative (reference :293 / :343)
+    const double ratio = rhs[i] / (-a);
+    if (bv > ratio) { bv = ratio; bi = i; }                // strict: lowest row on ties (:297 / :347)
+  }
+}
+
+// 3. the column with the largest bound, evaluated exactly by all workgroups together (ratio partials)
+__global__ __launch_bounds__(kPartialThreads) void k_prb_first(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const double* __restrict__ rhsv,
+    const double* __restrict__ pv, const int64_t* __restrict__ pi, const int64_t* __restrict__ pfirst, int n_part,
+    PrbInfo* __restrict__ info, double* __restrict__ rv, int64_t* __restrict__ ri) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (!prb_step_alive(st, steps, j)) return;
+  double u1;
+  int64_t l1;
+  fold_partials<true, kPartialThreads>(pv, pi, n_part, u1, l1, s_v, s_i);
+  double fv = 0.0;
+  int64_t fi = -1;
+  for (int k = threadIdx.x; k < n_part; k += kPartialThreads) {
+    const int64_t f = pfirst[k];
+    if (f >= 0) take_max(fv, fi, -(double)f, f);
+  }
+  block_arg<true, kPartialThreads>(fv, fi, s_v, s_i);
+  if (threadIdx.x == 0) s_i[0] = fi;
+  __syncthreads();
+  fi = s_i[0];
+  __syncthreads();
+  if (l1 < 0) l1 = fi;           // no column has a bound: start from the lowest candidate
+  if (blockIdx.x == 0 && threadIdx.x == 0) { info->l1 = (int32_t)l1; info->first = (int32_t)fi; }
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  if (l1 >= 0)
+    prb_column_min(T, sh, (int)l1, j, colp, rowp, rstride, prb_rhs(T, sh, rhsv, j), (int64_t)blockIdx.x * kPartialThreads + threadIdx.x,
+                   (int64_t)gridDim.x * kPartialThreads, bv, bi);
+  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) { rv[blockIdx.x] = bv; ri[blockIdx.x] = bi; }
+}
+
+// 4. exact score s1 of that column; the columns whose bound reaches it are listed for exact evaluation
+__global__ __launch_bounds__(kPartialThreads) void k_prb_list(
+    Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ obj, const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part,
+    const double* __restrict__ ub, const uint8_t* __restrict__ ucand, PrbInfo* __restrict__ info,
+    int32_t* __restrict__ elist, double* __restrict__ escore, int64_t* __restrict__ erow) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (!prb_step_alive(st, steps, j)) return;
+  const int l1 = info->l1;
+  if (l1 < 0) return;
+  double min1;
+  int64_t row1;
+  fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, min1, row1, s_v, s_i);
+  const double s1 = row1 >= 0 ? __dmul_rn(obj[l1], min1) : -DBL_MAX;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { info->s1 = s1; escore[l1] = s1; erow[l1] = row1; }
+  for (int l0 = blockIdx.x * kPartialThreads; l0 < sh.nloc; l0 += gridDim.x * kPartialThreads) {
+    const int l = l0 + threadIdx.x;
+    const bool take = l < sh.nloc && l != l1 && ucand[l] != 0 && ub[l] >= s1;
+    const unsigned long long mask = __ballot(take);
+    if (mask) {
+      const int lane = threadIdx.x & (kWave - 1);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&info->n_list, __popcll(mask));
+      base = __shfl(base, 0, kWave);
+      if (take) elist[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+    }
+  }
+}
+
+// 5. exact evaluation of the listed columns.  A short list (the usual case: a handful of columns) is spread
+// over the chip, one workgroup per column and slice of rows, and leaves ratio partials per slice; a long
+// one (nothing could be ruled out) takes one workgroup per column at a time and leaves the results.
+constexpr int kPrbSliced = 64;     // longest list evaluated in slices
+constexpr int kPrbSlices = 128;    // most slices per column
+
+__global__ __launch_bounds__(kPartialThreads) void k_prb_eval(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ obj, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
+    const double* __restrict__ rhsv, const PrbInfo* __restrict__ info, const int32_t* __restrict__ elist,
+    double* __restrict__ escore, int64_t* __restrict__ erow, int n_slices, double* __restrict__ ep_v, int64_t* __restrict__ ep_i) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (!prb_step_alive(st, steps, j)) return;
+  const int n_list = info->n_list;
+  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
+  if (n_list <= kPrbSliced) {
+    for (int w = blockIdx.x; w < n_list * n_slices; w += gridDim.x) {
+      const int l = elist[w / n_slices], slice = w % n_slices;
+      double bv = DBL_MAX;
+      int64_t bi = -1;
+      prb_column_min(T, sh, l, j, colp, rowp, rstride, rhs, (int64_t)slice * kPartialThreads + threadIdx.x,
+                     (int64_t)n_slices * kPartialThreads, bv, bi);
+      block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+      if (threadIdx.x == 0) { ep_v[w] = bv; ep_i[w] = bi; }
+    }
+    return;
+  }
+  for (int k = blockIdx.x; k < n_list; k += gridDim.x) {
+    const int l = elist[k];
+    double bv = DBL_MAX;
+    int64_t bi = -1;
+    prb_column_min(T, sh, l, j, colp, rowp, rstride, rhs, threadIdx.x, kPartialThreads, bv, bi);
+    block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+    if (threadIdx.x == 0) {
+      escore[l] = bi >= 0 ? __dmul_rn(obj[l], bv) : -DBL_MAX;
+      erow[l] = bi;
+    }
+  }
+}
+
+// 6. the reference's fold (lp_simplex_tableau.cc:310-325 / 353-362) over the exact results: largest score
+// among columns that have a row, lowest column on ties; no such column: the lowest candidate with row -1
+// (=> unbounded); no candidate: gcol -1 (=> optimal).  A later step of the chain records its entering
+// column for k_chain_finalize (step 0 hands the record to k_pivot_finalize; k_prb_pick_rows has settled the budget).
+__global__ __launch_bounds__(kPartialThreads) void k_prb_pick(
+    Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ obj, const PrbInfo* __restrict__ info, const int32_t* __restrict__ elist,
+    double* __restrict__ escore, int64_t* __restrict__ erow, int n_slices, const double* __restrict__ ep_v,
+    const int64_t* __restrict__ ep_i, Candidate* __restrict__ cand) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  if (!prb_step_alive(st, steps, j)) return;
+  const int l1 = info->l1, n_list = info->n_list;
+  if (n_list <= kPrbSliced) {     // a short list was evaluated in slices: one wavefront folds the slices of a column
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int k = wave; k < n_list; k += kPartialThreads / kWave) {
+      double mv = DBL_MAX;
+      int64_t mi = -1;
+      for (int q = lane; q < n_slices; q += kWave) take_min(mv, mi, ep_v[k * n_slices + q], ep_i[k * n_slices + q]);
+      wave_arg<false>(mv, mi);
+      if (lane == 0) {
+        const int l = elist[k];
+        escore[l] = mi >= 0 ? __dmul_rn(obj[l], mv) : -DBL_MAX;
+        erow[l] = mi;
+      }
+    }
+    __syncthreads();
+  }
+  double bv = -DBL_MAX;
+  int64_t bi = -1;
+  for (int k = threadIdx.x; k <= n_list; k += kPartialThreads) {
+    const int l = k == n_list ? l1 : elist[k];
+    if (l >= 0 && erow[l] >= 0) take_max(bv, bi, escore[l], (int64_t)l);
+  }
+  block_arg<true, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0) {
+    Candidate c;
+    if (bi >= 0) {
+      c.key = bv; c.gcol = gcol_of(bi * sh.world + sh.rank, sh.N); c.row = erow[bi]; c.ce = obj[bi];
+    } else if (info->first >= 0) {
+      c.key = -DBL_MAX; c.gcol = gcol_of((int64_t)info->first * sh.world + sh.rank, sh.N); c.row = -1; c.ce = obj[info->first];
+    } else {
+      c.key = -DBL_MAX; c.gcol = -1; c.row = -1; c.ce = 0.0;
+    }
+    *cand = c;
+    PrbInfo* winfo = const_cast<PrbInfo*>(info);        // nothing else runs in this launch
+    winfo->priced += 1;
+    winfo->listed += n_list;
+    if (j == 0) st->n_active = 0;                       // the set-up appends the active list from zero
+    else if (c.gcol >= 0 && c.row >= 0) { steps[j].e = c.gcol; steps[j].ce = c.ce; }
+  }
+}
+
+}  // namespace lpamd

@@ -71,6 +71,7 @@ def library():
         "lpamd_pass_stats": (ctypes.c_int, [vp, P(ctypes.c_int32), P(i64), P(i64)]),
         "lpamd_profile_totals": (ctypes.c_int, [vp, P(ctypes.c_double), P(i64), P(i64), P(i64), P(i64)]),
         "lpamd_loop_depth": (ctypes.c_int, [vp, i32, P(i32)]),
+        "lpamd_pricing_stats": (ctypes.c_int, [vp, P(i64), P(i64)]),
         "lpamd_local_candidate": (ctypes.c_int, [vp, i32, vp]),
         "lpamd_select_candidate": (ctypes.c_int, [vp, i32, vp, i32, P(i64), P(i64), P(i32), P(i32)]),
         "lpamd_fold_candidates": (ctypes.c_int, [i32, vp, i32, i64, P(i64), P(i64), P(i32), P(i32), vp]),
@@ -310,6 +311,12 @@ class TableauEngine:
         ms, a, b, c, d = ctypes.c_double(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
         _ck(self.L.lpamd_profile_totals(self.h, ctypes.byref(ms), ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
         return ms.value, a.value, b.value, c.value, d.value
+
+    def pricing_stats(self):
+        """MAX_REDUCTION pricing from bounds: (pricings done, candidate columns evaluated exactly over all rows)."""
+        a, b = ctypes.c_int64(), ctypes.c_int64()
+        _ck(self.L.lpamd_pricing_stats(self.h, ctypes.byref(a), ctypes.byref(b)))
+        return a.value, b.value
 
     def loop_depth(self, strategy):
         d = ctypes.c_int32()

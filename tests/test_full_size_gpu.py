@@ -127,25 +127,28 @@ def test_m32768_n65536_two_chained_passes_bit_exact(lpamd, monkeypatch):
 
 def test_m65536_n262144_max_reduction_properties_and_fused_pricing(lpamd, monkeypatch):
     """BASELINE's largest configuration on one GPU (172 GB stored): max-reduction pricing (reference
-    lp_simplex_tableau.cc:235-374) fused into the update against the separate pricing pass, the
+    lp_simplex_tableau.cc:235-374) from bounds (the default) against the full pricing fused into the update, the
     size-independent properties of the tableau after the pivots, and the storage-free oracle (pivot
     sequence, objective row, right-hand side, sampled columns bit for bit)."""
     m, n, seed, k = 65536, 262144, 1, 4
     N = n + m
     rng = np.random.default_rng(1)
 
-    def run(fuse):
-        monkeypatch.setenv("LPAMD_FUSE_PR", "1" if fuse else "0")
+    def run(bounds):
+        # bounds: the default loop (pricing from bounds, a chain of pivots per pass); otherwise one pivot per pass with
+        # the pricing of every column fused into the update
+        monkeypatch.setenv("LPAMD_PR_BOUNDS", "1" if bounds else "0")
         eng = lpamd.TableauEngine(m, N)
-        monkeypatch.delenv("LPAMD_FUSE_PR")
+        monkeypatch.delenv("LPAMD_PR_BOUNDS")
+        assert (eng.loop_depth(lpamd.MAX_REDUCTION) > 1) == bounds
         eng.fill_synthetic(n, seed)
         for j in list(rng.integers(0, n, 2)) + [n + 7, N]:       # generator spot checks against the oracle's entry function
             col = eng.read_column(int(j))
             for i in rng.integers(0, m, 6):
                 assert col[i] == lo.lib().lpo_synth_entry(seed, m, n, int(i), int(j))
         objs = [eng.objective_constant()]
-        for _ in range(k):
-            assert eng.run_pivots(lpamd.MAX_REDUCTION, 1) == (lpamd.LIMIT, 1)
+        for leg in ((3, 1) if bounds else (1, 1, 1, 1)):       # the chained loop applies the first three pivots in one pass
+            assert eng.run_pivots(lpamd.MAX_REDUCTION, leg) == (lpamd.LIMIT, leg)
             objs.append(eng.objective_constant())
         assert all(b > a for a, b in zip(objs, objs[1:])), "objective must increase on this non-degenerate LP"
         trace = eng.trace()
@@ -167,8 +170,8 @@ def test_m65536_n262144_max_reduction_properties_and_fused_pricing(lpamd, monkey
 
     fused = run(True)
     plain = run(False)
-    assert fused[0] == plain[0], "fused max-reduction pricing changed the pivot sequence"
-    assert fused[1] == plain[1]
+    assert fused[0] == plain[0], "pricing from bounds changed the pivot sequence"
+    assert fused[1][-1] == plain[1][-1]
     assert np.array_equal(bits(fused[2]), bits(plain[2])) and np.array_equal(bits(fused[3]), bits(plain[3]))
     for j in fused[4]:
         assert np.array_equal(bits(fused[4][j]), bits(plain[4][j])), "column %d" % j
