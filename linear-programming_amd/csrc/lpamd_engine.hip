@@ -487,7 +487,7 @@ int enqueue_chain_update(lpamd_engine* e);
 
 // MAX_REDUCTION pricing of step j of a pass from bounds (six small launches, no pass over the tableau): the
 // candidate record (column, row, score) lands in `cand`.
-int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand) {
+int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_step = true) {
   const int n_seg = (int)std::min<int64_t>(kPrbSegments, e->sh.m);   // segments of the rows whose minima give the threshold
   double* sm_v = e->prb_v;
   double* pv = e->prb_v + kMaxPartials;
@@ -519,7 +519,7 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand) {
                      e->prb_ep_i);
   LP_TRY(check_launch("k_prb_eval"));
   hipLaunchKernelGGL(k_prb_pick, dim3(1), dim3(kPartialThreads), 0, e->stream, e->sh, e->st, e->steps, j, e->obj, e->prb_info, e->prb_elist,
-                     e->prb_escore, e->prb_erow, n_slices, e->prb_ep_v, e->prb_ep_i, cand);
+                     e->prb_escore, e->prb_erow, n_slices, e->prb_ep_v, e->prb_ep_i, cand, record_step ? 1 : 0);
   return check_launch("k_prb_pick");
 }
 
@@ -537,6 +537,37 @@ int enqueue_prb_pass(lpamd_engine* e) {
   }
   e->price_partials_fresh = false;
   return enqueue_chain_update(e);
+}
+
+// Column shards, MAX_REDUCTION from bounds.  Step j = the pivots already set up in this pass.
+// 1. this rank's best candidate (exact score, row) and its column, packed into `slot` for the exchange
+int prb_shard_price(lpamd_engine* e, uint64_t* slot, int header_words) {
+  const int j = e->update_pending ? e->pending_steps : 0;
+  Candidate* rec = reinterpret_cast<Candidate*>(slot);
+  LP_TRY(enqueue_prb_pricing(e, j, rec, false));
+  hipLaunchKernelGGL(k_prb_export, dim3((unsigned)((e->sh.lda + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0, e->stream, e->T,
+                     e->sh, e->st, e->steps, j, e->colp, e->rowp, e->rstride, rec, reinterpret_cast<double*>(slot + header_words));
+  return check_launch("k_prb_export");
+}
+// 2. set-up of that step for the winner among all ranks: record in `cand` (the engine's own for step 0, where the
+// fold has settled the status as well), its column in `xbuf`
+int prb_shard_setup(lpamd_engine* e, const Candidate* cand, const double* xbuf) {
+  const int j = e->update_pending ? e->pending_steps : 0;
+  if (j >= e->chain_depth) return set_err(LPAMD_E_STATE, "the pass already holds %d pivots", j);
+  e->apply_since_pull++;
+  LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
+  if (j == 0) {
+    LP_TRY(enqueue_finalize(e, false, cand, xbuf, -1));
+    e->update_pending = true;
+    e->pending_steps = 1;
+    return LPAMD_OK;
+  }
+  hipLaunchKernelGGL((k_chain_finalize<false, false>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh,
+                     e->st, e->steps, j, nullptr, nullptr, 0, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, xbuf, cand, e->obj,
+                     e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i);
+  LP_TRY(check_launch("k_chain_finalize"));
+  e->pending_steps++;
+  return LPAMD_OK;
 }
 
 // The further pivots of a pass and the pass itself, for the pivot that k_pivot_finalize has just set up.
@@ -800,8 +831,8 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
   HIP_TRY(hipMalloc(&e->colv, sizeof(double) * e->sh.lda));
-  // MAX_REDUCTION prices from bounds wherever pivots chain (world == 1; column shards keep the in-order exchange)
-  e->pr_bounds = e->chain_depth > 1 && world == 1;
+  // MAX_REDUCTION prices from bounds wherever pivots chain
+  e->pr_bounds = e->chain_depth > 1;
   if (const char* env = getenv("LPAMD_PR_BOUNDS")) e->pr_bounds = e->pr_bounds && atoi(env) != 0;
   if (e->pr_bounds) {
     HIP_TRY(hipMalloc(&e->prb_info, sizeof(PrbInfo)));

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_pick(
     Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
     const double* __restrict__ obj, const PrbInfo* __restrict__ info, const int32_t* __restrict__ elist,
     double* __restrict__ escore, int64_t* __restrict__ erow, int n_slices, const double* __restrict__ ep_v,
-    const int64_t* __restrict__ ep_i, Candidate* __restrict__ cand) {
+    const int64_t* __restrict__ ep_i, Candidate* __restrict__ cand, int record_step) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (!prb_step_alive(st, steps, j)) return;
@@ -447,8 +447,30 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_pick(
     winfo->priced += 1;
     winfo->listed += n_list;
     if (j == 0) st->n_active = 0;                       // the set-up appends the active list from zero
-    else if (c.gcol >= 0 && c.row >= 0) { steps[j].e = c.gcol; steps[j].ce = c.ce; }
+    else if (record_step && c.gcol >= 0 && c.row >= 0) { steps[j].e = c.gcol; steps[j].ce = c.ce; }   // column shards: the winner among all ranks is recorded after the exchange
   }
+}
+
+// Column shards: this rank's candidate record (k_prb_pick) and that column as the pivots set up so far leave
+// it, packed for the exchange.  A step that may not be set up any more (budget, chain ended) sends "no candidate".
+__global__ __launch_bounds__(kPartialThreads) void k_prb_export(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
+    Candidate* __restrict__ slot_cand, double* __restrict__ slot_col) {
+  if (st->status != ST_RUNNING) return;
+  if (!prb_step_alive(st, steps, j)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { slot_cand->gcol = -1; slot_cand->row = -1; }
+    return;
+  }
+  const int64_t e = slot_cand->gcol;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= sh.lda) return;
+  double v = 0.0;
+  if (e >= 0 && i < sh.m) {
+    const int l = (int)(ordinal_of(e, sh.N) / sh.world);      // a local column by construction
+    v = chain_apply(T.col(l)[i], j, colp + i, sh.lda, rowp + l, rstride);
+  }
+  slot_col[i] = v;
 }
 
 }  // namespace lpamd

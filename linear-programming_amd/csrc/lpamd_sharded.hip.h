@@ -55,10 +55,13 @@ __global__ __launch_bounds__(256) void k_export_candidate(
 // status (budget, optimum, unbounded; reference lp_simplex_tableau.cc:201-205, 230-233, 365-373)
 // and keeps the winner in the engine's own candidate.  Otherwise (look-ahead loop): runs next to
 // the rank-1 update, touches no pivot state; "no candidate" travels as gcol = -1.
+// chain_steps / chain_j (look-ahead form only): a MAX_REDUCTION winner of step chain_j >= 1 of a pass is
+// recorded for k_chain_finalize here, after the exchange, if that step may still be set up.
 template <bool kInOrder>
 __global__ __launch_bounds__(256) void k_pick_winner(
     const uint64_t* __restrict__ slots, int world, int64_t slot_words, Shape sh, int max_reduction,
-    PivotState* __restrict__ st, Candidate* __restrict__ cand_out, double* __restrict__ xbuf) {
+    PivotState* __restrict__ st, Candidate* __restrict__ cand_out, double* __restrict__ xbuf,
+    ChainStep* __restrict__ chain_steps, int chain_j) {
   __shared__ int s_w;
   if (kInOrder && st->status != ST_RUNNING) return;
   if (threadIdx.x == 0) {
@@ -81,6 +84,10 @@ __global__ __launch_bounds__(256) void k_pick_winner(
         else *cand_out = best;
       } else {
         *cand_out = best;
+        if (chain_steps && chain_j >= 1 && w >= 0 && best.row >= 0 && prb_step_alive(st, chain_steps, chain_j)) {
+          chain_steps[chain_j].e = best.gcol;
+          chain_steps[chain_j].ce = best.ce;
+        }
       }
     }
   }
@@ -343,7 +350,7 @@ int exchange_lookahead(Group* g, Shard& s, bool on_x) {
   }
   LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, st));
   hipLaunchKernelGGL(k_pick_winner<false>, dim3((unsigned)((g->lda + 255) / 256)), dim3(256), 0, st, s.slots, g->world, g->slot_words,
-                     e->sh, 0, e->st, e->cand_la, s.xbuf);
+                     e->sh, 0, e->st, e->cand_la, s.xbuf, nullptr, 0);
   LP_TRY(check_launch("k_pick_winner"));
   if (on_x) HIP_TRY(hipEventRecord(s.ev_arrived, s.xstream));
   return LPAMD_OK;
@@ -415,7 +422,7 @@ int run_in_order(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* resul
       LP_TRY(check_launch("k_export_candidate"));
       LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
       hipLaunchKernelGGL(k_pick_winner<true>, dim3((unsigned)((g->lda + 255) / 256)), dim3(256), 0, e->stream, s.slots, g->world,
-                         g->slot_words, e->sh, strategy == LPAMD_MAX_REDUCTION ? 1 : 0, e->st, e->cand, s.xbuf);
+                         g->slot_words, e->sh, strategy == LPAMD_MAX_REDUCTION ? 1 : 0, e->st, e->cand, s.xbuf, nullptr, 0);
       LP_TRY(check_launch("k_pick_winner"));
       LP_TRY(lpamd_apply_pivot(e, strategy, -1, -1, s.xbuf));
     }
@@ -430,8 +437,53 @@ int run_in_order(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* resul
   return LPAMD_OK;
 }
 
+// MAX_REDUCTION from bounds (lpamd_prbound_kernels.hip.h): every rank prices its own columns (a few rows per
+// column, exact evaluation of what the bounds leave), the ranks trade record + column in one all-gather, and
+// the winner is set up on entries rebuilt through the pivots before it: a chain of pivots per pass here too.
+int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done) {
+  lpamd_engine* e = s.eng;
+  int64_t start = 0;
+  LP_TRY(lpamd_pivot_count(e, &start));
+  if (k == 0) { *result = LPAMD_LIMIT; *done = 0; return LPAMD_OK; }
+  LP_TRY(lpamd_set_pivot_budget(e, k));
+  const unsigned pick_grid = (unsigned)((g->lda + 255) / 256);
+  int64_t enqueued = 0;
+  int32_t res = LPAMD_LIMIT;
+  for (;;) {
+    const int64_t n = k < 0 ? g->poll_every : std::min<int64_t>(g->poll_every, k - enqueued);
+    const int64_t passes = (n + g->chain - 1) / g->chain;
+    for (int64_t p = 0; p < passes; p++) {
+      for (int j = 0; j < g->chain; j++) {
+        LP_TRY(prb_shard_price(e, s.slot, kSlotHeaderWords));
+        LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
+        if (j == 0) {   // the fold settles budget / optimum / unbounded and keeps the winner in the engine's candidate
+          hipLaunchKernelGGL(k_pick_winner<true>, dim3(pick_grid), dim3(256), 0, e->stream, s.slots, g->world, g->slot_words, e->sh, 1, e->st,
+                             e->cand, s.xbuf, nullptr, 0);
+          LP_TRY(check_launch("k_pick_winner"));
+          LP_TRY(prb_shard_setup(e, e->cand, s.xbuf));
+        } else {
+          hipLaunchKernelGGL(k_pick_winner<false>, dim3(pick_grid), dim3(256), 0, e->stream, s.slots, g->world, g->slot_words, e->sh, 1, e->st,
+                             e->cand_la, s.xbuf, e->steps, j);
+          LP_TRY(check_launch("k_pick_winner"));
+          LP_TRY(prb_shard_setup(e, e->cand_la, s.xbuf));
+        }
+      }
+      LP_TRY(lpamd_lookahead_update(e));
+    }
+    enqueued += passes * g->chain;
+    LP_TRY(lpamd_poll(e, &res));
+    if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
+  }
+  int64_t now = 0;
+  LP_TRY(lpamd_pivot_count(e, &now));
+  *result = res;
+  *done = now - start;
+  return LPAMD_OK;
+}
+
 int run_pivots_shard(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
   if (strategy == LPAMD_MAX_COST) return run_lookahead(g, s, k, result, done);
+  if (strategy == LPAMD_MAX_REDUCTION && s.eng->pr_bounds && g->chain > 1) return run_reduction_chain(g, s, k, result, done);
   if (strategy == LPAMD_MAX_REDUCTION) return run_in_order(g, s, strategy, k, result, done);
   return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
 }

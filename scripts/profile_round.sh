@@ -1,14 +1,57 @@
 #!/bin/bash
-# bench + rocprofv3 kernel stats + the two PMC passes of the default configuration (run on the GPU box)
+# Everything profiles/roundN/ holds, in one run on the GPU box (about 8 minutes):
+#   bash scripts/profile_round.sh && cp gpurun_out/prof_round/* profiles/roundN/
 set -e
 export TMPDIR=/tmp
-o=gpurun_out/prof_chain
+o=gpurun_out/prof_round
 rm -rf $o; mkdir -p $o
-timeout -k 10 300 python3 -u bench.py > $o/bench_default.json
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $o/stats -- python3 bench.py --no-cpu-baseline > $o/bench_under_rocprof.json
-timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline > $o/pmc_fetch.json
-timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 16 --warmup 8 --no-cpu-baseline > $o/pmc_write.json
-python3 scripts/pmc_traffic.py $o/pmc_fetch $o/pmc_write synthetic_m32768_n65536 8 > $o/pmc_hbm_traffic_m32768_n65536.json
-find $o/stats -name "*kernel_stats.csv" -exec cp {} $o/kernel_stats.csv \;
-rm -rf $o/stats/*/*kernel_trace.csv $o/pmc_fetch $o/pmc_write
-cat $o/bench_default.json; head -8 $o/kernel_stats.csv; cat $o/pmc_hbm_traffic_m32768_n65536.json
+stats() {   # stats <name> <bench args...>: rocprofv3 kernel stats of one bench command
+  local name=$1; shift
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/st_$name -- python3 bench.py --no-cpu-baseline "$@" > $o/${name}_under_rocprof.json 2>> $o/err.log
+  find $o/st_$name -name "*kernel_stats.csv" -exec cp {} $o/${name}_kernel_stats.csv \;
+  rm -rf $o/st_$name
+}
+pmc() {     # pmc <name> <bench args...>: the two PMC passes and their reduction
+  local name=$1; shift
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
+  python3 scripts/pmc_traffic.py $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json > $o/pmc_hbm_traffic_$name.json
+  rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json $o/pmc_write.json
+}
+# the default line (with the CPU baseline) and the driver's own invocation
+timeout -k 10 300 python3 -u bench.py > $o/bench_default_m32768_n65536.json 2>> $o/err.log
+timeout -k 10 300 python3 -u bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_default_steps20_warmup5.json 2>> $o/err.log
+stats bench_default_m32768_n65536
+pmc m32768_n65536
+# max-reduction, same configuration
+timeout -k 10 300 python3 -u bench.py --strategy max_reduction --no-cpu-baseline > $o/bench_max_reduction_m32768_n65536.json 2>> $o/err.log
+stats bench_max_reduction_m32768_n65536 --strategy max_reduction
+pmc max_reduction_m32768_n65536 --strategy max_reduction
+# one pivot per pass (the roofline of a single rank-1 update)
+LPAMD_CHAIN=1 timeout -k 10 300 python3 -u bench.py --no-cpu-baseline > $o/bench_one_pivot_per_pass_m32768_n65536.json 2>> $o/err.log
+# the other BASELINE sizes on one GPU
+for strat in max_cost max_reduction; do
+  timeout -k 10 300 python3 -u bench.py --config synthetic_m4096_n8192 --strategy $strat --steps 960 --warmup 96 --no-cpu-baseline > $o/bench_m4096_n8192_$strat.json 2>> $o/err.log
+  timeout -k 10 400 python3 -u bench.py --config synthetic_m65536_n262144 --strategy $strat --steps 32 --warmup 16 --no-cpu-baseline > $o/bench_m65536_n262144_1gpu_$strat.json 2>> $o/err.log
+done
+# rank 0 of an N-GPU run alone on this GPU (RCCL world of one)
+for w in 2 4 8; do
+  LPAMD_BENCH_SHARD_OF=$w timeout -k 10 300 python3 -u bench.py --steps 512 --warmup 64 --no-cpu-baseline > $o/shard_of_${w}_max_cost.json 2>> $o/err.log
+done
+LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --strategy max_reduction --steps 256 --warmup 64 --no-cpu-baseline > $o/shard_of_8_max_reduction.json 2>> $o/err.log
+LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --config synthetic_m65536_n262144 --strategy max_reduction --steps 64 --warmup 32 --no-cpu-baseline > $o/shard_of_8_m65536_n262144_max_reduction.json 2>> $o/err.log
+LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_cost --steps 512 --warmup 64
+python3 - <<'PY'
+import glob, json
+for f in sorted(glob.glob("gpurun_out/prof_round/*.json")):
+    try:
+        d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+    except Exception as ex:
+        print(f, "unreadable", ex); continue
+    if "metric" in d:
+        r = d["roofline"]
+        print("%-62s %10.1f pivots/s  %8.4f ms/pivot  pass %8.3f ms  %7.1f GB/s frac %.3f traffic %s" % (
+            f.split("/")[-1], d["value"], d["ms_per_step"], r["avg_launch_ms"], r["achieved"], r["frac"], r["traffic"]))
+    else:
+        print("%-62s traffic/streamed %.4f" % (f.split("/")[-1], d["traffic_over_streamed"]))
+PY
