@@ -48,11 +48,12 @@ DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 
 
-def pmc_traffic_ratio(config, world, chained):
+def pmc_traffic_ratio(config, world, chained, strategy):
     """HBM bytes the update kernel really moved per byte it is meant to stream, from the committed
     rocprofv3 PMC passes of this same command (profiles/*/pmc_hbm_traffic_*.json: FETCH_SIZE doubled
     as gfx950 requires, plus WRITE_SIZE; one pass per counter).  The newest file for the
-    configuration and the kind of pass (chain of pivots or one pivot) wins; None if there is none."""
+    configuration, the pricing strategy and the kind of pass (chain of pivots or one pivot) wins; None if
+    there is none."""
     import glob
     if world != 1:
         return None, None
@@ -62,7 +63,8 @@ def pmc_traffic_ratio(config, world, chained):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("config") == config and (d.get("pivots_per_launch", 1) > 1) == chained and d.get("traffic_over_streamed"):
+        if (d.get("config") == config and d.get("strategy", "max_cost") == strategy
+                and (d.get("pivots_per_launch", 1) > 1) == chained and d.get("traffic_over_streamed")):
             best, src = float(d["traffic_over_streamed"]), os.path.relpath(f, ROOT)
     return best, src
 
@@ -229,7 +231,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)   # report the slowest rank's kernel rate
         achieved = float(t.item())
     chained = passes > 0 and pivots > passes
-    ratio, ratio_src = pmc_traffic_ratio(args.config, world, chained)
+    ratio, ratio_src = pmc_traffic_ratio(args.config, world, chained, args.strategy)
     per_launch = streamed_bytes / max(passes, 1)
 
     out = {

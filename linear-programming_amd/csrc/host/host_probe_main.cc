@@ -1,7 +1,7 @@
 // lp_host_probe <mode> <file>: prints intermediate states of the host layer so
 // that CPU-only tests can compare them with the strings the reference's own
 // unit tests expect (parser_test.cc, lp_test.cc) and with the oracle's tableau.
-//   tokens | parse | standard | slack | tableau | mps2txt
+//   tokens | parse | standard | slack | tableau | mps2txt | expand
 #include <cinttypes>
 #include <cstring>
 #include <fstream>
@@ -10,13 +10,25 @@
 #include "lp_model.h"
 #include "lp_text.h"
 #include "mps_text.h"
+#include "netlib_text.h"
 
 int main(int argc, char** argv) {
   if (argc < 3) {
-    std::cerr << "usage: " << argv[0] << " tokens|parse|standard|slack|tableau|mps2txt <file>\n";
+    std::cerr << "usage: " << argv[0] << " tokens|parse|standard|slack|tableau|mps2txt|expand <file>\n";
     return 2;
   }
   const std::string mode = argv[1], path = argv[2];
+  if (mode == "expand") {   // netlib's compressed form -> MPS text
+    std::ifstream f(path);
+    if (!f.is_open()) { std::cerr << "cannot open " << path << "\n"; return 2; }
+    try {
+      std::cout << ExpandNetlib(f, path);
+    } catch (const std::exception& ex) {
+      std::cerr << ex.what() << "\n";
+      return 3;
+    }
+    return 0;
+  }
   if (mode == "mps2txt") {
     std::cout << MpsToLpText(path);
     return 0;

@@ -3,6 +3,8 @@
 // problem variables sorted by name when the bound lines are written).
 #include "mps_text.h"
 
+#include "netlib_text.h"
+
 #include <algorithm>
 #include <cstdio>
 #include <fstream>
@@ -41,6 +43,14 @@ std::string WriteExpression(const Terms& terms, double constant, const std::map<
 std::string MpsToLpText(const std::string& mps_path) {
   std::ifstream in(mps_path);
   if (!in.is_open()) throw std::runtime_error("Cannot find file\n");
+  if (LooksLikeCompressedNetlib(in)) {   // netlib's compressed form: expand it first (tools/preprocessing.sh:2-9)
+    std::istringstream mps(ExpandNetlib(in, mps_path));
+    return MpsStreamToLpText(mps);
+  }
+  return MpsStreamToLpText(in);
+}
+
+std::string MpsStreamToLpText(std::istream& in) {
   std::vector<std::pair<char, std::string>> rows;   // sense, name (objective row excluded)
   std::map<std::string, Terms> row_terms;
   std::map<std::string, double> rhs;

@@ -4,6 +4,9 @@
 // that the parser sees byte-identical input and the tableau matches the
 // reference's datasets/netlib/<name>.txt.
 #pragma once
+#include <istream>
 #include <string>
 
+// `mps_path` may also hold netlib's compressed form (netlib_text.h), which is expanded first.
 std::string MpsToLpText(const std::string& mps_path);
+std::string MpsStreamToLpText(std::istream& mps);

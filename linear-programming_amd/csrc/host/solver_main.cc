@@ -4,7 +4,8 @@
 // and prints the optimum followed by `name = value` lines (reference
 // solver.cc:123-171).  The other algorithms belong to the reference's CPU-only
 // solvers and are rejected.  A file ending in .mps is first converted the way the reference's
-// tools/mps_load.py does.  --gpus N deals the tableau columns over N GPUs (RCCL inside the engine;
+// tools/mps_load.py does, and a file in netlib's compressed form (datasets/netlib/<name> as shipped) is
+// expanded to MPS before that, as tools/emps.c does.  --gpus N deals the tableau columns over N GPUs (RCCL inside the engine;
 // LPAMD_GPUS=N does the same without touching the command line); --shards K keeps K column shards on
 // GPU 0 with an in-process exchange, which walks the same multi-GPU code on a one-GPU machine.
 #include <algorithm>
@@ -17,6 +18,7 @@
 #include "lp_model.h"
 #include "lp_text.h"
 #include "mps_text.h"
+#include "netlib_text.h"
 
 namespace {
 
@@ -73,10 +75,10 @@ static int Run(int argc, char** argv) {
 
   Parser parser;
   Model model = {{}, OptimizationObject(FLOAT)};
-  if (EndsWith(Lower(path), ".mps")) {
+  std::ifstream file(path);
+  if (EndsWith(Lower(path), ".mps") || (file.is_open() && LooksLikeCompressedNetlib(file))) {
     model = parser.Parse(MpsToLpText(path));
   } else {
-    std::ifstream file(path);
     model = parser.Parse(file);
   }
   // An LP whose constraints mention no FLOAT variable is an integer program

@@ -9,6 +9,8 @@ only sees the committed result).  Everything copied is DATA the reference's own 
                                         ships but its ctest skips, "takes too long", CMakeLists.txt:138)
   netlib_mps/<name>.mps              <- datasets/netlib/<name> decoded with oracle/_ref/emps
                                         (the reference's tools/emps.c compiled by `make -C oracle ref`)
+  netlib_compressed/<name>           <- datasets/netlib/<name> as shipped (netlib's compressed form; the input of
+                                        the product's own expander, whose output must equal netlib_mps/<name>.mps)
 
 usage: python tests/golden/make_fixtures.py [--out DIR] [--reference /root/reference]
 With --out pointing elsewhere the committed fixtures can be checked with `diff -r`."""
@@ -28,6 +30,7 @@ NETLIB = {"netlib_sol_max_cost": ("netlib_simplex_sol", ["afiro", "adlittle", "k
           "netlib_sol_revised": ("netlib_revised_simplex_sol", ["afiro", "adlittle", "kb2", "israel"]),
           "netlib_sol_revised_extra": ("netlib_revised_simplex_sol", ["agg", "agg2", "agg3"])}
 MPS = ["afiro", "adlittle", "kb2", "israel", "agg", "agg2", "agg3", "fit1d"]
+COMPRESSED = MPS + ["25fv47"]   # 25fv47 has no solution golden upstream; it is the largest expansion case
 
 
 def main():
@@ -51,7 +54,9 @@ def main():
         for n in names:
             shutil.copyfile(os.path.join(ref, "datasets", src_dir, n + ".txt"), os.path.join(a.out, dst, n + ".txt"))
     os.makedirs(os.path.join(a.out, "netlib_mps"), exist_ok=True)
-    for n in MPS:
+    os.makedirs(os.path.join(a.out, "netlib_compressed"), exist_ok=True)
+    for n in COMPRESSED:
+        shutil.copyfile(os.path.join(ref, "datasets", "netlib", n), os.path.join(a.out, "netlib_compressed", n))
         with open(os.path.join(ref, "datasets", "netlib", n), "rb") as fin, open(os.path.join(a.out, "netlib_mps", n + ".mps"), "wb") as fout:
             subprocess.run([emps], stdin=fin, stdout=fout, check=True)
 

@@ -120,3 +120,13 @@ def test_solver_cli_gpus_one_and_env(tmp_path):
     out = subprocess.run([os.path.join(BIN, "solver"), _path("test15"), "simplex_tableau", "max_cost", "--gpus", "64"],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode != 0 and "visible" in out.stderr
+
+
+@pytest.mark.parametrize("name,strategy", [("afiro", "max_cost"), ("kb2", "max_reduction"), ("israel", "max_cost")])
+def test_solver_cli_reads_netlib_files_as_shipped(name, strategy):
+    """datasets/netlib/<name> in netlib's compressed form (upstream: tools/emps.c, then tools/mps_load.py,
+    tools/preprocessing.sh:2-9) goes straight into the CLI."""
+    out = subprocess.run([os.path.join(BIN, "solver"), os.path.join(GOLDEN, "netlib_compressed", name), "simplex_tableau", strategy],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.rstrip("\n") == case_golden(name, strategy).rstrip("\n")

@@ -57,3 +57,43 @@ def test_kb2_bounds_become_rows():
 def test_solver_cli_rejects_other_algorithms():
     out = subprocess.run([os.path.join(BIN, "solver"), _path("test12"), "simplex"], capture_output=True, text=True)
     assert out.returncode == 2 and out.stdout == "Error\n"
+
+
+COMPRESSED = sorted(os.listdir(os.path.join(GOLDEN, "netlib_compressed")))
+
+
+@pytest.mark.parametrize("name", COMPRESSED)
+def test_netlib_expansion_is_byte_identical_to_the_reference_tool(name):
+    """netlib_compressed/<name> is the file the reference ships; netlib_mps/<name>.mps is what the
+    reference's tools/emps.c (compiled once, tests/golden/make_fixtures.py) printed for it."""
+    got = subprocess.check_output([os.path.join(BIN, "lp_host_probe"), "expand", os.path.join(GOLDEN, "netlib_compressed", name)])
+    assert got == open(os.path.join(GOLDEN, "netlib_mps", name + ".mps"), "rb").read()
+
+
+@pytest.mark.parametrize("name", [n for n in COMPRESSED if n != "25fv47"])
+def test_compressed_netlib_file_converts_like_its_mps(name):
+    got = subprocess.check_output([os.path.join(BIN, "lp_host_probe"), "mps2txt", os.path.join(GOLDEN, "netlib_compressed", name)]).decode()
+    assert got == mt.mps_to_text(_path(name))
+
+
+def test_netlib_expansion_rejects_damaged_files(tmp_path):
+    data = open(os.path.join(GOLDEN, "netlib_compressed", "afiro"), "rb").read()
+    lines = data.split(b"\n")
+    probe = os.path.join(BIN, "lp_host_probe")
+    # one symbol of a data line changed: the checksum line no longer matches
+    bad = list(lines)
+    bad[4] = bad[4][:3] + (b"A" if bad[4][3:4] != b"A" else b"B") + bad[4][4:]
+    p = tmp_path / "flipped"
+    p.write_bytes(b"\n".join(bad))
+    out = subprocess.run([probe, "expand", str(p)], capture_output=True, text=True)
+    assert out.returncode == 3 and ("check sum" in out.stderr or "line" in out.stderr)
+    # cut in the middle
+    p = tmp_path / "cut"
+    p.write_bytes(b"\n".join(lines[: len(lines) // 2]) + b"\n")
+    out = subprocess.run([probe, "expand", str(p)], capture_output=True, text=True)
+    assert out.returncode == 3 and "premature end" in out.stderr
+    # two problems in one file expand one after the other
+    p = tmp_path / "twice"
+    p.write_bytes(data + data)
+    out = subprocess.run([probe, "expand", str(p)], capture_output=True)
+    assert out.returncode == 0 and out.stdout == 2 * open(_path("afiro"), "rb").read()
