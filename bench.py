@@ -258,7 +258,7 @@ def main():
         "pivots_per_pass": round(pivots / max(passes, 1), 3),
         "algorithmic_GBps": round(algo_bytes / secs / 1e9, 1) if passes else 0.0,
         **({"max_reduction_pricing": {"pricings": priced, "columns_evaluated_exactly": evaluated,
-                                      "note": "since the engine was created (the first pricing evaluates every candidate column)"}} if priced else {}),
+                                      "note": "since the engine was created (warm-up included)"}} if priced else {}),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": round(ratio * per_launch) if ratio else None,
