@@ -46,6 +46,7 @@ CONFIGS = {
 }
 DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+FP64_VECTOR_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # one fp64 add or multiply per lane and clock, 16 lanes per SIMD
 
 
 def pmc_traffic_ratio(config, world, chained, strategy):
@@ -195,7 +196,7 @@ def main():
         group.fill_synthetic(n, args.seed)
         eng = group.engine(0)
         run = lambda k: group.run_pivots(strat, k)
-        depth = group.chain() if strat == lp.MAX_COST else 1
+        depth = group.chain()
         exchange = "one RCCL all-gather per pivot (record + candidate column per rank), inside the library"
 
     K, W = args.steps, args.warmup
@@ -263,9 +264,15 @@ def main():
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": round(ratio * per_launch) if ratio else None,
                      "traffic_source": ratio_src,
-                     "kernel": "k_update_slab" if chained else "k_update", "avg_launch_ms": round(upd_ms / max(passes, 1), 5),
+                     "kernel": ("k_update_deep" if pivots > 16 * passes else "k_update_slab") if chained else "k_update",
+                     "avg_launch_ms": round(upd_ms / max(passes, 1), 5),
                      "launches": int(passes), "streamed_bytes_per_launch": per_launch,
                      "algorithmic_bytes_per_launch": algo_bytes / max(passes, 1),
+                     "fp64_vector": {"achieved_Tops": round(2.0 * m * touched_cols / secs / 1e12, 2) if passes else 0.0,
+                                     "peak_Tops": FP64_VECTOR_PEAK_TOPS, "frac": round(2.0 * m * touched_cols / secs / 1e12 / FP64_VECTOR_PEAK_TOPS, 4) if passes else 0.0,
+                                     "note": "separately rounded multiply + add per entry and chained pivot (no FMA: the reference rounds twice); "
+                                             "peak = 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz; beyond 16 pivots per pass this, "
+                                             "not HBM, bounds the pass (plus one v_min3_f32 per two entries and step for the 1e-6 drop)"},
                      "note": "achieved = HBM bytes one launch streams (16*m per column it reads and writes, once per pass) / its "
                              "duration (HIP events on the engine's stream); a launch applies pivots_per_pass pivots to every entry, "
                              "so the per-pivot algorithmic bytes (16*m*n_active per pivot) give algorithmic_GBps, which may exceed the "

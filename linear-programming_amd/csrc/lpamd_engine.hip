@@ -73,6 +73,8 @@ struct lpamd_engine {
   int32_t loop_depth = 1;       // depth of the device loop that ran last
   int32_t slab_shape = 0;       // k_update_slab variant (0: k_update_chain)
   int32_t slab_grid = 4096;
+  int32_t deep_batch = 0;       // > 0: k_update_deep with that many columns per batch (chains longer than 16)
+  int32_t deep_grid = 4096;
   int64_t rstride = 0;
   ChainStep* steps = nullptr;   // [kMaxChain]
   double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
@@ -454,12 +456,36 @@ bool launch_slab_shape(lpamd_engine* e) {
     default: return false;
   }
 }
+// col' in LDS, steps in the outer loop (chains longer than 16): 128 rows per workgroup, batches of deep_batch columns
+template <int kC>
+void launch_deep(lpamd_engine* e) {
+  const int n_slabs = (int)(e->sh.lda / (2 * kWave));
+  const int n_grp = std::max(1, e->deep_grid / n_slabs);
+  const size_t lds = sizeof(double2) * kWave * (size_t)e->chain_depth;
+  if (e->update_nt)
+    hipLaunchKernelGGL((k_update_deep<kC, true>), dim3(n_slabs * n_grp), dim3(kDeepThreads), lds, e->stream, e->T, e->sh.lda, e->colp, e->pass,
+                       e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis,
+                       n_slabs);
+  else
+    hipLaunchKernelGGL((k_update_deep<kC, false>), dim3(n_slabs * n_grp), dim3(kDeepThreads), lds, e->stream, e->T, e->sh.lda, e->colp, e->pass,
+                       e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis,
+                       n_slabs);
+}
+bool launch_update_deep(lpamd_engine* e) {
+  switch (e->deep_batch) {
+    case 4: launch_deep<4>(e); return true;
+    case 8: launch_deep<8>(e); return true;
+    default: return false;
+  }
+}
+
 bool launch_update_slab(lpamd_engine* e) {
   // the instantiated chain lengths; a chain shorter than the template takes the step-by-step path of the kernel
   if (e->chain_depth <= 4) return launch_slab_shape<4>(e);
   if (e->chain_depth <= 8) return launch_slab_shape<8>(e);
   if (e->chain_depth <= 12) return launch_slab_shape<12>(e);
-  return launch_slab_shape<16>(e);
+  if (e->chain_depth <= 16) return launch_slab_shape<16>(e);
+  return false;   // longer chains do not fit the registers: k_update_deep, or k_update_chain with col' from L2
 }
 
 // Step j >= 1 of a chain: ratio partials (pricing fold + rebuilt column on one GPU; candidate record + column
@@ -591,11 +617,12 @@ int enqueue_chain_update(lpamd_engine* e) {
     HIP_TRY(hipEventRecord(e0, e->stream));
   }
   hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + 255) / 256)), dim3(256), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
-                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth);
+                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->deep_batch);
   LP_TRY(check_launch("k_chain_list"));
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
   const int grid = e->update_grid;
-  if (launch_update_slab(e)) { /* col' in registers */ }
+  if (launch_update_deep(e)) { /* col' in LDS */ }
+  else if (launch_update_slab(e)) { /* col' in registers */ }
   else if (n_slabs >= 16) launch_update_chain<16>(e, grid, e->update_nt);
   else if (n_slabs >= 8) launch_update_chain<8>(e, grid, e->update_nt);
   else if (n_slabs >= 4) launch_update_chain<4>(e, grid, e->update_nt);
@@ -796,7 +823,13 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
   // Longer columns: a pivot is bound by the HBM pass, so a chain of pivots shares one (see k_update_chain)
   // (column shards chain through lpamd_chain_step, the caller runs the exchange of every step)
-  e->chain_depth = !e->two_launch ? 16 : 1;
+  // Depth: 16 steps still hide under the HBM time of the pass (k_update_slab, col' in registers).  Beyond that the
+  // pass is bound by the fp64 vector rate (two instructions per entry and step plus the magnitude tracking) and
+  // grows by 0.18 ms per step at m=32768 n=65536 while a step's set-up costs 0.03 ms: 24 steps (k_update_deep,
+  // 6.35 ms per pass against 5.65) give 3400 pivots/s against 2630, 32 steps 3600 at 8 ms per pass.  Shards that
+  // fit the Infinity Cache are bound by the set-up launches and stay at 16.
+  const bool hbm_sized = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
+  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 24 : 16);
   if (const char* env = getenv("LPAMD_CHAIN")) {
     e->chain_depth = std::max(1, std::min(kMaxChain, atoi(env)));
     if (e->chain_depth > 1) e->two_launch = false;
@@ -806,6 +839,10 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->slab_shape = e->sh.lda % 1024 == 0 ? 4 : 1;
   if (const char* env = getenv("LPAMD_SLAB")) e->slab_shape = atoi(env);
   if (const char* env = getenv("LPAMD_SLAB_GRID")) e->slab_grid = std::max(1, atoi(env));
+  e->deep_batch = (e->chain_depth > 16 && e->sh.lda % (2 * kWave) == 0) ? 8 : 0;
+  if (const char* env = getenv("LPAMD_DEEP")) e->deep_batch = (e->chain_depth > 1 && e->sh.lda % (2 * kWave) == 0) ? atoi(env) : 0;
+  if (e->deep_batch != 4 && e->deep_batch != 8) e->deep_batch = 0;
+  if (const char* env = getenv("LPAMD_DEEP_GRID")) e->deep_grid = std::max(1, atoi(env));
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
   } else {
@@ -856,7 +893,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (e->chain_depth > 1) {
     HIP_TRY(hipMalloc(&e->list_full, sizeof(int32_t) * e->ncl));
     HIP_TRY(hipMalloc(&e->list_part, sizeof(int32_t) * e->ncl));
-    HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)e->ncl * e->chain_depth));
+    HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)(e->ncl + 8) * e->chain_depth));   // whole batches of up to 8 columns
     HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->chain_depth));
   }
   HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * e->sh.lda, e->stream));    // rows beyond m stay zero

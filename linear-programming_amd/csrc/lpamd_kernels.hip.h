@@ -53,7 +53,7 @@ struct PivotState {  // device resident, one per engine
   int32_t l_e, l_d;  // local columns of e and d on this rank (-1: another rank's, or none)
 };
 
-constexpr int kMaxChain = 16;   // pivots one pass over the tableau may apply
+constexpr int kMaxChain = 32;   // pivots one pass over the tableau may apply
 
 struct ChainStep {   // pivots 1.. of the pass (pivot 0 is described by PivotState)
   int32_t done;      // 1 once k_chain_finalize has set the step up
@@ -872,15 +872,23 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   }
 }
 
+// Where row'_s of the k-th column of list_full lives when the runs are laid out for k_update_deep: the columns
+// in batches of c, inside a batch the c values of one step next to each other.
+__device__ __forceinline__ int64_t deep_run_index(int k, int s, int depth, int c) {
+  return (int64_t)(k / c) * depth * c + (int64_t)s * c + (k % c);
+}
+
 // Once per pass, after the last set-up: the columns the pass has to stream, split into those that
 // every step touches (list_full; the pass applies the chain to them without a single test) and those
 // that some step leaves alone (list_part: entering and leaving columns of the chain, mostly), and
 // the row' values of every listed column side by side (rsl_*[k * stride + s] = row'_s of the k-th
-// listed column, zero beyond the chain), which the pass reads as one short run per column.
+// listed column, zero beyond the chain), which the pass reads as one short run per column.  batch > 0: list_full's
+// runs in the layout of deep_run_index instead.
 __global__ __launch_bounds__(256) void k_chain_list(
     const double* __restrict__ rowp, int64_t rstride, int depth, const ChainStep* __restrict__ steps,
     const PivotState* __restrict__ st, int ncl, PassInfo* __restrict__ pass,
-    int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride) {
+    int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride,
+    int batch) {
   if (st->status != ST_RUNNING) return;
   int n_steps = 1;
   while (n_steps < depth && steps[n_steps].done) n_steps++;
@@ -907,8 +915,12 @@ __global__ __launch_bounds__(256) void k_chain_list(
     const unsigned long long below = (1ull << lane) - 1ull;
     const int k = full ? bf + __popcll(mf & below) : bp + __popcll(mp & below);
     (full ? list_full : list_part)[k] = l;
-    double* __restrict__ out = (full ? rsl_full : rsl_part) + (int64_t)k * stride;
-    for (int s = 0; s < stride; s++) out[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
+    if (full && batch > 0) {   // batches of `batch` columns, the values of one step side by side (k_update_deep)
+      for (int s = 0; s < stride; s++) rsl_full[deep_run_index(k, s, stride, batch)] = s < n_steps ? rowp[s * rstride + l] : 0.0;
+    } else {
+      double* __restrict__ out = (full ? rsl_full : rsl_part) + (int64_t)k * stride;
+      for (int s = 0; s < stride; s++) out[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
+    }
   }
 }
 
@@ -932,6 +944,19 @@ __device__ __forceinline__ void chain_bookkeeping(PivotState* st, ChainStep* ste
     st->e = z.e; st->r = z.r; st->d = z.d; st->a = z.a; st->ce = z.ce; st->f = z.f; st->g = z.g;
   }
 }
+
+// Smallest magnitude seen so far, tracked on the HIGH words of the doubles read as floats: for values of one
+// sign the bit pattern of a double grows with its magnitude, so does the pattern of its upper half, and a float
+// minimum with |.| on its inputs orders those patterns (one instruction for two entries; exponents that would read
+// as float NaNs belong to magnitudes above 2^1017 and are skipped, which is what a minimum wants).  The test
+// `pattern <= upper half of the threshold` errs to the safe side: it also fires for the few values whose upper half
+// equals the threshold's and whose lower half lies above it.
+__device__ __forceinline__ float min_magnitude_high(float acc, double a, double b) {
+  float out;
+  asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(out) : "v"(acc), "v"(__double2hiint(a)), "v"(__double2hiint(b)));
+  return out;
+}
+constexpr uint32_t kDropHigh = (uint32_t)(__builtin_bit_cast(uint64_t, (double)1e-6f) >> 32);
 
 // The pass with the col' vectors read from L2 per column (any chain length, any column length).
 template <int kUnroll, bool kNT>
@@ -989,8 +1014,8 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
 //
 // Full chain over list_full: no test per step.  The drop of |v| < 1e-6 after every add (reference
 // lp_simplex_tableau.cc:5-8) is taken out of the inner loop: the chain is first evaluated WITHOUT
-// the drop while the smallest |v| seen on the way is tracked (multiply, add, minimum: three
-// instructions per entry and step instead of five).  If no lane saw a value below the threshold,
+// the drop while the smallest |v| seen on the way is tracked (multiply and add per entry, one minimum per two
+// entries: 2.5 instructions per entry and step instead of five).  If no lane saw a value below the threshold,
 // no drop would have happened and the result is exactly the reference's; otherwise the wavefront
 // redoes that column from the loaded values with the drop in place.  A drop is rare (the entering
 // column of every step takes it, hardly anything else in a dense tableau).
@@ -1020,7 +1045,6 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
       c[s][r].x = c[s][r].y = 0.0;
       if (s < n_steps) c[s][r] = cp[s * n_vec + v0 + r * kUpdateThreads];
     }
-  const double kDrop = (double)1e-6f;
   int k0 = grp * kC;
   if (n_steps == kK) {
     for (; k0 + kC <= pass.n_full; k0 += n_grp * kC) {
@@ -1036,19 +1060,21 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
 #pragma unroll
       for (int u = 0; u < kC; u++) {
         const double* __restrict__ rs = rsl_full + (int64_t)(k0 + u) * stride;
-        double mx = DBL_MAX, my = DBL_MAX;
+        float low = FLT_MAX;
 #pragma unroll
         for (int s = 0; s < kK; s++) {
           const double rj = rs[s];
 #pragma unroll
-          for (int r = 0; r < kR; r++) {
-            t[u][r].x = __dadd_rn(t[u][r].x, __dmul_rn(c[s][r].x, rj));
-            t[u][r].y = __dadd_rn(t[u][r].y, __dmul_rn(c[s][r].y, rj));
-            mx = fmin(mx, fabs(t[u][r].x));
-            my = fmin(my, fabs(t[u][r].y));
+          for (int r = 0; r < kR; r++) {   // products first, then the minimum over what the step before left
+            const double px = __dmul_rn(c[s][r].x, rj), py = __dmul_rn(c[s][r].y, rj);
+            if (s > 0) low = min_magnitude_high(low, t[u][r].x, t[u][r].y);
+            t[u][r].x = __dadd_rn(t[u][r].x, px);
+            t[u][r].y = __dadd_rn(t[u][r].y, py);
           }
         }
-        if (__any(fmin(mx, my) < kDrop)) {   // a value below the threshold on the way: this column again, with the drop
+#pragma unroll
+        for (int r = 0; r < kR; r++) low = min_magnitude_high(low, t[u][r].x, t[u][r].y);
+        if (__any(__float_as_uint(low) <= kDropHigh)) {   // a value below the threshold on the way: this column again, with the drop
 #pragma unroll
           for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);   // not stored yet
           // row' is fetched again through an offset the compiler cannot see through: otherwise it keeps all the
@@ -1093,6 +1119,118 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
 #pragma unroll
       for (int r = 0; r < kR; r++) st16<kNT>(p + r * kUpdateThreads, w[r]);
     }
+  }
+}
+
+// The pass for chains longer than the registers hold (depth > 16).  A wavefront can issue one vector instruction
+// every four to five cycles while its SIMD executes an fp64 multiply or add every 2.4, so the arithmetic of a long
+// chain only reaches the SIMD's rate with three or four wavefronts resident, and k_update_slab's col' slices
+// (4*depth registers per lane) leave room for two.  Here the col' slices of a workgroup's 128 rows sit in LDS
+// (depth KiB), shared by its eight wavefronts, which deal the batches of kC columns among themselves; a wavefront
+// walks the STEPS in its outer loop: col'_s of its rows is one LDS read, the kC row' values of the step one scalar
+// load (the runs are stored batch by batch for that, deep_run_index), and the kC columns give 2*kC independent
+// add chains per lane.  The entries of the next batch are requested before the current one is worked on.
+// The |v| < 1e-6 drop is handled as in k_update_slab: evaluated without it while the smallest magnitude per column
+// is tracked, and a column that saw one is redone from memory with the drop in place.
+constexpr int kDeepThreads = 512;
+template <int kC, bool kNT>
+__global__ __launch_bounds__(kDeepThreads, 2) void k_update_deep(
+    Tab T, int64_t lda, const double* __restrict__ colp, const PassInfo* __restrict__ passp,
+    const int32_t* __restrict__ list_full, const int32_t* __restrict__ list_part,
+    const double* __restrict__ rsl_full, const double* __restrict__ rsl_part, int depth,
+    PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
+    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis, int n_slabs) {
+  extern __shared__ double2 s_c[];   // [n_steps][kWave]
+  if (st->status != ST_RUNNING) return;
+  const PassInfo pass = *passp;
+  const int n_steps = pass.n_steps;
+  if (n_steps <= 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) chain_bookkeeping(st, steps, pass, sh, is_basic, basis);
+  const int slab = blockIdx.x % n_slabs, grp = blockIdx.x / n_slabs, n_grp = gridDim.x / n_slabs;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int n_vec = (int)(lda / 2);
+  const int v0 = slab * kWave + lane;
+  const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
+  for (int q = threadIdx.x; q < n_steps * kWave; q += kDeepThreads)
+    s_c[q] = cp[(int64_t)(q / kWave) * n_vec + slab * kWave + (q % kWave)];
+  __syncthreads();
+  constexpr int kWaves = kDeepThreads / kWave;
+  const int stream = grp * kWaves + wave, n_streams = n_grp * kWaves;   // this wavefront: batches stream, stream + n_streams, ...
+  auto column = [&](int k) { return reinterpret_cast<double2*>(T.col(list_full[k])) + v0; };
+  const int n_batches = n_steps == depth ? pass.n_full / kC : 0;
+  int b = stream;
+  if (b < n_batches) {
+    double2 t[kC];
+#pragma unroll
+    for (int u = 0; u < kC; u++) t[u] = ld16<kNT>(column(b * kC + u));
+    for (; b < n_batches; b += n_streams) {
+      // the same loads every round (the last one fetches its own batch again, unused): a load under a condition
+      // would make the compiler wait for all outstanding loads before the first use of the current batch
+      const int bn = b + n_streams < n_batches ? b + n_streams : b;
+      double2 tn[kC];
+#pragma unroll
+      for (int u = 0; u < kC; u++) tn[u] = ld16<kNT>(column(bn * kC + u));
+      const double* __restrict__ rb = rsl_full + (int64_t)b * depth * kC;
+      float low[kC];
+#pragma unroll
+      for (int u = 0; u < kC; u++) low[u] = FLT_MAX;
+      // The operands of a step (col'_s of the rows: one LDS read; the kC row' values: one scalar load) are requested
+      // one step ahead into a second set of registers, and only AFTER the current step has laid hands on its own
+      // set: scalar loads return out of order, so every wait for one is a wait for all outstanding, and
+      // a request issued before that wait would be waited for on the spot.
+      auto step = [&](const double2& cs, const double (&rj)[kC], double2& cs_ahead, double (&rj_ahead)[kC], int s_ahead) {
+        asm volatile("" : : "v"(cs.x), "s"(rj[kC - 1]));   // the current set has arrived (a use the compiler cannot move)
+        __builtin_amdgcn_sched_barrier(0);
+        cs_ahead = s_c[s_ahead * kWave + lane];
+#pragma unroll
+        for (int u = 0; u < kC; u++) rj_ahead[u] = rb[s_ahead * kC + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kC; u++) {
+          const double px = __dmul_rn(cs.x, rj[u]), py = __dmul_rn(cs.y, rj[u]);
+          low[u] = min_magnitude_high(low[u], t[u].x, t[u].y);   // what the step before left (a stored entry is 0 or large)
+          t[u].x = __dadd_rn(t[u].x, px);
+          t[u].y = __dadd_rn(t[u].y, py);
+        }
+      };
+      double2 cs_a = s_c[lane], cs_b;
+      double rj_a[kC], rj_b[kC];
+#pragma unroll
+      for (int u = 0; u < kC; u++) rj_a[u] = rb[u];
+      int s = 0;
+      for (; s + 2 <= depth; s += 2) {
+        step(cs_a, rj_a, cs_b, rj_b, s + 1);
+        step(cs_b, rj_b, cs_a, rj_a, s + 2 < depth ? s + 2 : s + 1);
+      }
+      if (s < depth) step(cs_a, rj_a, cs_b, rj_b, s);
+#pragma unroll
+      for (int u = 0; u < kC; u++) {
+        low[u] = min_magnitude_high(low[u], t[u].x, t[u].y);
+        double2* __restrict__ p = column(b * kC + u);
+        if (__any(__float_as_uint(low[u]) <= kDropHigh)) {   // this column again, with the drop
+          double2 w = ld16<kNT>(p);                           // not stored yet
+          for (int s = 0; s < depth; s++) w = rank1(w, s_c[s * kWave + lane], rb[s * kC + u]);
+          t[u] = w;
+        }
+        st16<kNT>(p, t[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < kC; u++) t[u] = tn[u];
+    }
+  }
+  // step by step: what is left of list_full (all of it when the chain ended early), then list_part
+  const int n_list = pass.n_full + pass.n_part;
+  for (int k = n_batches * kC + stream; k < n_list; k += n_streams) {
+    const bool in_full = k < pass.n_full;
+    const int l = in_full ? list_full[k] : list_part[k - pass.n_full];
+    double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l)) + v0;
+    double2 w = ld16<kNT>(p);
+    for (int s = 0; s < n_steps; s++) {
+      const double rj = in_full ? rsl_full[deep_run_index(k, s, depth, kC)] : rsl_part[(int64_t)(k - pass.n_full) * depth + s];
+      if (rj != 0.0) w = rank1(w, s_c[s * kWave + lane], rj);
+    }
+    st16<kNT>(p, w);
   }
 }
 

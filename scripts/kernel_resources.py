@@ -11,7 +11,7 @@ names, rows = [], []
 for m in re.finditer(r"remark: Function Name: (\S+)", txt):
     names.append((m.start(), m.group(1)))
 names.append((len(txt), None))
-dem = subprocess.run(["c++filt"] + [n for _, n in names[:-1]], capture_output=True, text=True).stdout.splitlines()
+dem = subprocess.run(["c++filt"] + [n for _, n in names[:-1]], capture_output=True, text=True, stdin=subprocess.DEVNULL).stdout.splitlines()
 for k, (pos, name) in enumerate(names[:-1]):
     body = txt[pos:names[k + 1][0]]
     d = dem[k].split("(")[0].replace("void lpamd::", "")

@@ -27,8 +27,11 @@ pmc m32768_n65536
 timeout -k 10 300 python3 -u bench.py --strategy max_reduction --no-cpu-baseline > $o/bench_max_reduction_m32768_n65536.json 2>> $o/err.log
 stats bench_max_reduction_m32768_n65536 --strategy max_reduction
 pmc max_reduction_m32768_n65536 --strategy max_reduction
-# one pivot per pass (the roofline of a single rank-1 update)
+# one pivot per pass (the roofline of a single rank-1 update), 16 per pass (the longest chain that hides under the
+# HBM time of the pass) and 32 per pass (bound by the fp64 vector rate)
 LPAMD_CHAIN=1 timeout -k 10 300 python3 -u bench.py --no-cpu-baseline > $o/bench_one_pivot_per_pass_m32768_n65536.json 2>> $o/err.log
+LPAMD_CHAIN=16 timeout -k 10 300 python3 -u bench.py --steps 96 --warmup 32 --no-cpu-baseline > $o/bench_16_pivots_per_pass_m32768_n65536.json 2>> $o/err.log
+LPAMD_CHAIN=32 timeout -k 10 300 python3 -u bench.py --steps 96 --warmup 32 --no-cpu-baseline > $o/bench_32_pivots_per_pass_m32768_n65536.json 2>> $o/err.log
 # the other BASELINE sizes on one GPU
 for strat in max_cost max_reduction; do
   timeout -k 10 300 python3 -u bench.py --config synthetic_m4096_n8192 --strategy $strat --steps 960 --warmup 96 --no-cpu-baseline > $o/bench_m4096_n8192_$strat.json 2>> $o/err.log

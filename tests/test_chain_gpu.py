@@ -12,7 +12,7 @@ from test_engine_parity import _random_tied_lp, assert_same_tableau, bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 3, 8, 16])
+@pytest.fixture(autouse=True, params=[2, 3, 8, 16, 32])
 def depth(request, monkeypatch):
     monkeypatch.setenv("LPAMD_CHAIN", str(request.param))
     return request.param
@@ -152,7 +152,7 @@ def test_default_loop_chains_long_columns(lpamd, monkeypatch, depth):
 
 
 @pytest.mark.parametrize("slab", [1, 2, 3, 4])
-@pytest.mark.parametrize("chain,nt", [(4, "0"), (8, "1"), (16, "0")])
+@pytest.mark.parametrize("chain,nt", [(4, "0"), (8, "1"), (16, "0"), (24, "1"), (32, "0")])
 def test_slab_pass_with_col_in_registers(lpamd, monkeypatch, depth, slab, chain, nt):
     """k_update_slab (col' slices in registers, a workgroup per row slab) against the oracle: full
     solve, so short chains at the end, columns a step leaves alone and list tails all occur."""
@@ -160,6 +160,7 @@ def test_slab_pass_with_col_in_registers(lpamd, monkeypatch, depth, slab, chain,
         pytest.skip("one run is enough")
     monkeypatch.setenv("LPAMD_CHAIN", str(chain))
     monkeypatch.setenv("LPAMD_SLAB", str(slab))
+    monkeypatch.setenv("LPAMD_DEEP", "0")
     monkeypatch.setenv("LPAMD_UPDATE_NT", nt)
     monkeypatch.setenv("LPAMD_SLAB_GRID", "24")
     m, n, seed = 2000, 900, 11
@@ -188,4 +189,28 @@ def test_update_stats_average_over_passes_of_different_length(lpamd, monkeypatch
     assert 6.5 * n <= active <= 6.5 * (n + 14)
     assert eng.pass_stats()[0] == 5
     eng.set_profiling(False)
+    eng.close()
+
+
+@pytest.mark.parametrize("batch", [4, 8])
+@pytest.mark.parametrize("chain,nt,grid", [(3, "0", 16), (16, "1", 64), (24, "0", 40), (32, "1", 2048), (32, "0", 1)])
+def test_deep_pass_with_col_in_lds(lpamd, monkeypatch, depth, batch, chain, nt, grid):
+    """k_update_deep (col' slices in LDS, steps in the outer loop, batches of columns dealt over the wavefronts)
+    against the oracle: full solve, so short chains at the end, columns a step leaves alone, list tails and
+    fewer batches than wavefronts all occur."""
+    if depth != 2:
+        pytest.skip("one run is enough")
+    monkeypatch.setenv("LPAMD_CHAIN", str(chain))
+    monkeypatch.setenv("LPAMD_DEEP", str(batch))
+    monkeypatch.setenv("LPAMD_UPDATE_NT", nt)
+    monkeypatch.setenv("LPAMD_DEEP_GRID", str(grid))
+    m, n, seed = 2000, 900, 11
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    want = dt.solve(lo.MAX_COST)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    res, npiv = eng.solve(lpamd.MAX_COST)
+    assert res == want == lpamd.SOLVED and npiv == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
     eng.close()

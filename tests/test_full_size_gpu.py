@@ -83,16 +83,17 @@ def _sample_columns(rng, n, N, trace, k):
 
 
 def test_m32768_n65536_two_chained_passes_bit_exact(lpamd, monkeypatch):
-    """The configuration of the headline benchmark at its own size: 32 pivots (two full passes of the
-    default chained loop) against the oracle (reference lp_simplex_tableau.cc:10-52, 188-227), every
-    entry of the 25.8 GB tableau included; then the same 32 pivots with one pass per pivot."""
-    m, n, seed, k = 32768, 65536, 1, 32
+    """The configuration of the headline benchmark at its own size: two full passes of the default
+    chained loop (48 pivots at 24 per pass) against the oracle (reference lp_simplex_tableau.cc:10-52, 188-227), every
+    entry of the 25.8 GB tableau included; then the same pivots with one pass per pivot."""
+    m, n, seed = 32768, 65536, 1
     N = n + m
     eng = lpamd.TableauEngine(m, N)          # default knobs
+    k = 2 * eng.loop_depth(lpamd.MAX_COST)
     eng.fill_synthetic(n, seed)
     assert eng.run_pivots(lpamd.MAX_COST, k) == (lpamd.LIMIT, k)
     pivots, streamed, touched = eng.pass_stats()
-    assert pivots >= 8, "the default loop is expected to chain pivots at this size"
+    assert pivots == k // 2 >= 16, "the default loop is expected to chain pivots at this size"
     dt = lo.DenseTableau.synthetic(m, n, seed)
     dt.s.skip_zero_cols = 1
     dt.s.fast_basis = 1
@@ -192,10 +193,11 @@ def test_m32768_n65536_as_eight_shards(lpamd):
     the library's own loop (lpamd_group_*), here on one GPU with the in-process exchange: two full
     chained passes; every shard walks the single-engine pivots, the RHS replicas stay bit-identical, and
     sampled columns, objective row and basis flags equal the single-engine loop's."""
-    m, n, seed, k = 32768, 65536, 1, 32
+    m, n, seed = 32768, 65536, 1
     N = n + m
     g = lpamd.ShardGroup(m, N, 8, devices=[0] * 8, local_exchange=True)
-    assert g.chain() >= 8
+    assert g.chain() >= 16
+    k = 2 * g.chain()
     g.fill_synthetic(n, seed)
     assert g.run_pivots(lpamd.MAX_COST, k) == (lpamd.LIMIT, k)
     one = lpamd.TableauEngine(m, N)
