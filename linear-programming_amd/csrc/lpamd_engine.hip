@@ -244,6 +244,10 @@ int allocate_tableau(lpamd_engine* e) {
     // add a spacer so that an attempt advances by at least 12 GB of the 32 GiB units.
     const size_t step = (size_t)12 << 30;
     for (int attempt = 0; attempt < 16 && !chosen; attempt++) {
+      // the search never takes the device near its limit: a candidate, its spacer and 4 GiB to spare must fit
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+      if (free_b < std::max(bytes[1], step) + ((size_t)4 << 30)) break;
       double* cand = nullptr;
       if (hipMalloc(&cand, bytes[1]) != hipSuccess) { (void)hipGetLastError(); break; }
       float pair = 0.f;
