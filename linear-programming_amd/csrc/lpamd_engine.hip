@@ -82,6 +82,8 @@ struct lpamd_engine {
   bool pr_bounds = false;
   PrbInfo* prb_info = nullptr;
   double* prb_c = nullptr;       // [kMaxChain * kPrbRows] col'_s at the rows of the bound
+  double* prb_cache = nullptr;   // [kPrbRows * nloc] rows of the bound, one slot each, row-major
+  bool prb_use_cache = true;
   double* prb_v = nullptr;       // [3 * kMaxPartials] partials: smallest right-hand sides, largest bounds
   int64_t* prb_i = nullptr;      // [3 * kMaxPartials]
   PrbRows* prb_rowbuf = nullptr; // rows that met the threshold of the row selection
@@ -534,11 +536,18 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_ste
   hipLaunchKernelGGL(k_prb_pick_rows, dim3(1), dim3(kWave), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next, e->colp,
                      e->prb_rowbuf, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
   LP_TRY(check_launch("k_prb_pick_rows"));
-  hipLaunchKernelGGL(k_prb_bounds, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
-                     e->rowp, e->rstride, e->prb_info, e->prb_c, e->prb_ub, e->prb_ucand, pv, pi, pf);
+  const bool cached = e->prb_use_cache;
+  if (cached) {
+    hipLaunchKernelGGL(k_prb_fill, dim3((unsigned)((e->sh.nloc + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0, e->stream, e->T,
+                       e->sh, e->st, e->steps, j, e->colp, e->rowp, e->rstride, e->prb_info, e->prb_cache);
+    LP_TRY(check_launch("k_prb_fill"));
+  }
+  const int n_bound_blocks = (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (e->sh.nloc + kWave - 1) / kWave));   // tiles of 64 columns
+  hipLaunchKernelGGL(k_prb_bounds, dim3(n_bound_blocks), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
+                     e->rowp, e->rstride, e->prb_info, e->prb_c, cached ? e->prb_cache : nullptr, e->prb_ub, e->prb_ucand, pv, pi, pf);
   LP_TRY(check_launch("k_prb_bounds"));
   hipLaunchKernelGGL(k_prb_first, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->colp, e->rowp,
-                     e->rstride, e->rhs_next, pv, pi, pf, e->n_price_part, e->prb_info, rv, ri);
+                     e->rstride, e->rhs_next, pv, pi, pf, n_bound_blocks, e->prb_info, rv, ri);
   LP_TRY(check_launch("k_prb_first"));
   hipLaunchKernelGGL(k_prb_list, dim3(e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->sh, e->st, e->steps, j, e->obj, rv, ri,
                      e->n_ratio_part, e->prb_ub, e->prb_ucand, e->prb_info, e->prb_elist, e->prb_escore, e->prb_erow);
@@ -879,6 +888,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->prb_info, sizeof(PrbInfo)));
     HIP_TRY(hipMemsetAsync(e->prb_info, 0, sizeof(PrbInfo), e->stream));
     HIP_TRY(hipMalloc(&e->prb_c, sizeof(double) * kMaxChain * kPrbRows));
+    HIP_TRY(hipMalloc(&e->prb_cache, sizeof(double) * kPrbRows * (size_t)std::max<int64_t>(1, e->sh.nloc)));
     HIP_TRY(hipMalloc(&e->prb_v, sizeof(double) * 3 * kMaxPartials));
     HIP_TRY(hipMalloc(&e->prb_i, sizeof(int64_t) * 3 * kMaxPartials));
     HIP_TRY(hipMalloc(&e->prb_rowbuf, sizeof(PrbRows)));
@@ -886,6 +896,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->prb_ep_v, sizeof(double) * kPrbSliced * kPrbSlices));
     HIP_TRY(hipMalloc(&e->prb_ep_i, sizeof(int64_t) * kPrbSliced * kPrbSlices));
     if (const char* env = getenv("LPAMD_PRB_ROWS")) e->prb_rows = std::max(1, std::min(kPrbRows, atoi(env)));
+    if (const char* env = getenv("LPAMD_PRB_CACHE")) e->prb_use_cache = atoi(env) != 0;
     HIP_TRY(hipMalloc(&e->prb_ub, sizeof(double) * e->ncl));
     HIP_TRY(hipMalloc(&e->prb_ucand, e->ncl));
     HIP_TRY(hipMalloc(&e->prb_elist, sizeof(int32_t) * e->ncl));
@@ -926,7 +937,7 @@ int lpamd_destroy(lpamd_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
   void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part,
-                  e->prb_info, e->prb_c, e->prb_v, e->prb_i, e->prb_rowbuf, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
+                  e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_rowbuf, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);

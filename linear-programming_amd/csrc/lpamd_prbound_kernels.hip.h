@@ -33,6 +33,16 @@ struct PrbInfo {
   int32_t rows[kPrbRows];
   double b[kPrbRows];      // right-hand side at those rows, as the pivots set up so far leave it
   int64_t priced, listed;  // running totals: pricings done, columns they evaluated exactly besides l1
+  // Row cache: R changes by a few rows from one pricing of a pass to the next, and gathering a row of a column-major
+  // tableau costs a 64-byte sector per column.  Every row of R is therefore gathered once, into a slot of a
+  // row-major side buffer, as the steps set up until then leave it (jf of them); the pricings after that read the
+  // slot (coalesced) and apply the steps since.  The slots are emptied at step 0: the pass has changed the tableau.
+  int32_t slot[kPrbRows];      // slot of row k of R
+  int32_t jf[kPrbRows];        // steps its slot already holds
+  int32_t slot_row[kPrbRows];  // row a slot holds (-1: none)
+  int32_t slot_jf[kPrbRows];
+  int32_t n_fill, pad;         // rows of R to gather in this pricing
+  int32_t fill_row[kPrbRows], fill_slot[kPrbRows];
 };
 
 // true while step j of the pass may still be set up (the same tests k_chain_ratio makes)
@@ -207,8 +217,33 @@ __global__ __launch_bounds__(kWave) void k_prb_pick_rows(
     }
   }
   __shared__ int64_t s_rows[kPrbRows];
+  __shared__ int32_t s_slot_row[kPrbRows], s_slot_jf[kPrbRows];
+  if (lane < kPrbRows) { s_slot_row[lane] = j == 0 ? -1 : info->slot_row[lane]; s_slot_jf[lane] = info->slot_jf[lane]; }
   if (lane < n_rows) { info->rows[lane] = (int32_t)mine; info->b[lane] = rhs[mine]; s_rows[lane] = mine; }
   __syncthreads();
+  // cache slots: a row that a slot holds keeps it; the others take the slots no row of R occupies, lowest first
+  int my_slot = -1;
+  if (lane < n_rows)
+    for (int q = 0; q < kPrbRows; q++)
+      if (s_slot_row[q] == (int32_t)mine) my_slot = q;
+  const bool hit = lane < n_rows && my_slot >= 0, miss = lane < n_rows && my_slot < 0;
+  unsigned used = 0;
+  for (int q = 0; q < kPrbRows; q++)
+    if (__any(hit && my_slot == q)) used |= 1u << q;
+  const unsigned long long missing = __ballot(miss);
+  const int nth = __popcll(missing & ((1ull << lane) - 1ull));
+  if (miss) {
+    unsigned free_slots = ~used;
+    for (int t = 0; t < nth; t++) free_slots &= free_slots - 1;
+    my_slot = __ffs(free_slots) - 1;       // n_rows <= kPrbRows slots: there is one
+    info->slot_row[my_slot] = (int32_t)mine;
+    info->slot_jf[my_slot] = j;
+    info->fill_row[nth] = (int32_t)mine;
+    info->fill_slot[nth] = my_slot;
+  }
+  if (lane < n_rows) { info->slot[lane] = my_slot; info->jf[lane] = hit ? s_slot_jf[my_slot] : j; }
+  if (j == 0 && lane < kPrbRows && lane >= n_rows) info->slot_row[lane] = -1;   // step 0 fills slots 0..n_rows-1
+  if (lane == 0) info->n_fill = __popcll(missing);
   for (int t = lane; t < n_rows * j; t += kWave) {     // independent loads, a few per lane
     const int k = t % n_rows, sidx = t / n_rows;
     prb_c[sidx * kPrbRows + k] = colp[(int64_t)sidx * sh.lda + s_rows[k]];
@@ -228,56 +263,119 @@ __device__ __forceinline__ bool prb_basic(int l, int j, const uint8_t* is_basic,
   return basic;
 }
 
+// 1d. the rows new to R, gathered into their cache slots for every local column as steps 0..j-1 leave them
+__global__ __launch_bounds__(kPartialThreads) void k_prb_fill(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info,
+    double* __restrict__ cache) {
+  if (!prb_step_alive(st, steps, j)) return;
+  const int n_fill = info->n_fill;
+  const int l = blockIdx.x * kPartialThreads + threadIdx.x;
+  if (n_fill <= 0 || l >= sh.nloc) return;
+  const double* __restrict__ col = T.col(l);
+  constexpr int kBatch = 8;
+  for (int q0 = 0; q0 < n_fill; q0 += kBatch) {
+    double v[kBatch];
+#pragma unroll
+    for (int q = 0; q < kBatch; q++) v[q] = q0 + q < n_fill ? col[info->fill_row[q0 + q]] : 0.0;   // independent sector loads
+#pragma unroll
+    for (int q = 0; q < kBatch; q++) {
+      if (q0 + q >= n_fill) break;
+      const int row = info->fill_row[q0 + q];
+      cache[(int64_t)info->fill_slot[q0 + q] * sh.nloc + l] = chain_apply(v[q], j, colp + row, sh.lda, rowp + l, rstride);
+    }
+  }
+}
+
 // 2. bound u_l per candidate column from the rows of R; per-workgroup arg-max (lowest column on ties)
-// and lowest candidate column.
+// and lowest candidate column.  A workgroup takes tiles of 64 columns; its four wavefronts share the rows of R
+// (a quarter each, combined through LDS): one thread per column and all rows is a chain of a few thousand dependent
+// instructions on a chip that this kernel fills with one wavefront per SIMD.
+constexpr int kPrbGroups = kPartialThreads / kWave;
+constexpr int kPrbPerGroup = kPrbRows / kPrbGroups;
 __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
     Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
     const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
     const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info, const double* __restrict__ prb_c,
+    const double* __restrict__ cache,   // nullptr: the rows are gathered from the tableau itself
     double* __restrict__ ub, uint8_t* __restrict__ ucand,
     double* __restrict__ pv, int64_t* __restrict__ pi, int64_t* __restrict__ pfirst) {
-  __shared__ double s_v[kPartialThreads / kWave];
-  __shared__ int64_t s_i[kPartialThreads / kWave];
+  __shared__ double s_mn[kPrbGroups][kWave];
   if (!prb_step_alive(st, steps, j)) return;
   const int n_rows = info->n_rows;
-  double bv = -DBL_MAX, fv = 0.0;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int k0 = grp * kPrbPerGroup;
+  int jf_min = j;
+  int jfs[kPrbPerGroup], slots[kPrbPerGroup];
+  double bs[kPrbPerGroup];
+#pragma unroll
+  for (int k = 0; k < kPrbPerGroup; k++) {
+    const bool live = k0 + k < n_rows;
+    jfs[k] = live ? (cache ? info->jf[k0 + k] : 0) : j;
+    slots[k] = live ? (cache ? info->slot[k0 + k] : info->rows[k0 + k]) : 0;   // slot of the cache, or the row itself
+    bs[k] = live ? info->b[k0 + k] : 0.0;
+    jf_min = min(jf_min, jfs[k]);
+  }
+  double bv = -DBL_MAX;
   int64_t bi = -1, fi = -1;
-  for (int l = blockIdx.x * kPartialThreads + threadIdx.x; l < sh.nloc; l += gridDim.x * kPartialThreads) {
-    const double c = obj[l];
-    const bool cand = !prb_basic(l, j, is_basic, st, steps) && is_pos(c);
-    ucand[l] = cand ? 1 : 0;
-    if (!cand) continue;
-    if (fi < 0) fi = l;
-    const double* __restrict__ col = T.col(l);
-    double a[kPrbRows];
+  const int n_tiles = (sh.nloc + kWave - 1) / kWave;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int l = tile * kWave + lane;
+    const double c = l < sh.nloc ? obj[l] : 0.0;
+    const bool cand = l < sh.nloc && !prb_basic(l, j, is_basic, st, steps) && is_pos(c);
+    double mn = DBL_MAX;   // no eligible row among this wavefront's rows
+    if (cand) {
+      double a[kPrbPerGroup];
 #pragma unroll
-    for (int k = 0; k < kPrbRows; k++) a[k] = k < n_rows ? col[info->rows[k]] : 0.0;
-    for (int s = 0; s < j; s++) {
-      const double r = rowp[s * rstride + l];
-      if (r == 0.0) continue;                  // the update leaves the column alone in that step
+      for (int k = 0; k < kPrbPerGroup; k++)
+        a[k] = k0 + k >= n_rows ? 0.0 : (cache ? cache[(int64_t)slots[k] * sh.nloc + l] : T.col(l)[slots[k]]);
+      constexpr int kBatch = 8;   // row' values fetched together: the steps depend on each other, their loads do not
+      for (int s0 = jf_min; s0 < j; s0 += kBatch) {
+        double r[kBatch];
 #pragma unroll
-      for (int k = 0; k < kPrbRows; k++) a[k] = flushz(__dadd_rn(a[k], __dmul_rn(prb_c[s * kPrbRows + k], r)));
-    }
-    double mn = DBL_MAX;
-    bool any = false;
+        for (int q = 0; q < kBatch; q++) r[q] = s0 + q < j ? rowp[(int64_t)(s0 + q) * rstride + l] : 0.0;
 #pragma unroll
-    for (int k = 0; k < kPrbRows; k++) {
-      if (k < n_rows && (float)a[k] <= -1e-6f) {
-        const double ratio = info->b[k] / (-a[k]);
-        if (!any || ratio < mn) mn = ratio;
-        any = true;
+        for (int q = 0; q < kBatch; q++) {
+          const int s = s0 + q;
+          if (s >= j || r[q] == 0.0) continue;   // the update leaves the column alone in that step
+#pragma unroll
+          for (int k = 0; k < kPrbPerGroup; k++)
+            if (s >= jfs[k]) a[k] = flushz(__dadd_rn(a[k], __dmul_rn(prb_c[s * kPrbRows + k0 + k], r[q])));   // a slot holds the steps before jf
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kPrbPerGroup; k++) {
+        if (k0 + k < n_rows && (float)a[k] <= -1e-6f) {
+          const double ratio = bs[k] / (-a[k]);
+          if (ratio < mn) mn = ratio;
+        }
       }
     }
-    const double u = any ? __dmul_rn(c, mn) : DBL_MAX;   // no eligible row in R: no bound
-    ub[l] = u;
-    // The column evaluated first should have a TIGHT bound, so that its exact score rules the others out; a column
-    // without a bound is listed for evaluation anyway and would make a poor yardstick.
-    if (any && u > bv) { bv = u; bi = l; }
+    s_mn[grp][lane] = mn;
+    __syncthreads();
+    if (grp == 0 && l < sh.nloc) {
+#pragma unroll
+      for (int g = 1; g < kPrbGroups; g++) mn = fmin(mn, s_mn[g][lane]);
+      const bool any = mn < DBL_MAX;
+      const double u = any ? __dmul_rn(c, mn) : DBL_MAX;   // no eligible row in R: no bound
+      ucand[l] = cand ? 1 : 0;
+      if (cand) {
+        ub[l] = u;
+        if (fi < 0) fi = l;
+        // The column evaluated first should have a TIGHT bound, so that its exact score rules the others out; a
+        // column without a bound is listed for evaluation anyway and would make a poor yardstick.
+        if (any && u > bv) { bv = u; bi = l; }
+      }
+    }
+    __syncthreads();
   }
-  block_arg<true, kPartialThreads>(bv, bi, s_v, s_i);
-  fv = fi < 0 ? 0.0 : -(double)fi;
-  block_arg<true, kPartialThreads>(fv, fi, s_v, s_i);
-  if (threadIdx.x == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; pfirst[blockIdx.x] = fi; }
+  if (grp == 0) {
+    wave_arg<true>(bv, bi);
+    double fv = fi < 0 ? 0.0 : -(double)fi;
+    wave_arg<true>(fv, fi);
+    if (lane == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; pfirst[blockIdx.x] = fi; }
+  }
 }
 
 // exact minimum ratio of local column l over the rows [i0, m) strided by `stride`, as the steps so far leave it

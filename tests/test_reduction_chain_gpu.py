@@ -15,7 +15,7 @@ from test_engine_parity import _random_tied_lp, assert_same_tableau, bits
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=[2, 5, 16])
+@pytest.fixture(autouse=True, params=[2, 5, 16, 32])
 def depth(request, monkeypatch):
     monkeypatch.setenv("LPAMD_CHAIN", str(request.param))
     return request.param
@@ -57,6 +57,26 @@ def test_random_lps_with_ties_max_reduction_chained(lpamd, seed):
 
 @pytest.mark.parametrize("m,n,seed", [(600, 1100, 7), (2000, 900, 11), (40, 2500, 3), (2500, 40, 2), (1, 5, 1), (3, 1, 1)])
 def test_synthetic_max_reduction_chained_to_the_optimum(lpamd, m, n, seed):
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    want = dt.solve(lo.MAX_REDUCTION)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    res, npiv = eng.solve(lpamd.MAX_REDUCTION)
+    assert res == want == lpamd.SOLVED and npiv == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+@pytest.mark.parametrize("cache,rows", [("0", 32), ("1", 3), ("0", 3), ("1", 9)])
+def test_bound_rows_from_the_cache_or_from_the_tableau(lpamd, monkeypatch, depth, cache, rows):
+    """The rows the bounds look at come from a row-major cache that keeps them across the pricings of a pass
+    (slots reused, evicted and refilled when few rows are allowed) or straight from the tableau: same pivots."""
+    if depth not in (5, 32):
+        pytest.skip("two depths are enough")
+    monkeypatch.setenv("LPAMD_PRB_CACHE", cache)
+    monkeypatch.setenv("LPAMD_PRB_ROWS", str(rows))
+    m, n, seed = 700, 1300, 5
     dt = lo.DenseTableau.synthetic(m, n, seed)
     want = dt.solve(lo.MAX_REDUCTION)
     eng = lpamd.TableauEngine(m, n + m)
