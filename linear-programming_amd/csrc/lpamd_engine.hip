@@ -74,7 +74,7 @@ struct lpamd_engine {
   int32_t slab_shape = 0;       // k_update_slab variant (0: k_update_chain)
   int32_t slab_grid = 4096;
   int32_t deep_batch = 0;       // > 0: k_update_deep with that many columns per batch (chains longer than 16)
-  int32_t deep_grid = 4096;
+  int32_t deep_grid = 8192;
   int64_t rstride = 0;
   ChainStep* steps = nullptr;   // [kMaxChain]
   double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
@@ -99,6 +99,7 @@ struct lpamd_engine {
   int32_t* list_full = nullptr; // [ncl] columns every step of the chain touches ...
   int32_t* list_part = nullptr; // [ncl] ... and columns some steps leave alone
   double* rsl_full = nullptr;   // [ncl * chain_depth] row' values of the listed columns, one run per column
+  uint64_t* ptr_full = nullptr; // [ncl + 8] addresses of the columns of list_full (k_update_deep)
   double* rsl_part = nullptr;
   int64_t slot_counter = 0;
   int device = 0;
@@ -471,11 +472,11 @@ void launch_deep(lpamd_engine* e) {
   if (e->update_nt)
     hipLaunchKernelGGL((k_update_deep<kC, true>), dim3(n_slabs * n_grp), dim3(kDeepThreads), lds, e->stream, e->T, e->sh.lda, e->colp, e->pass,
                        e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis,
-                       n_slabs);
+                       n_slabs, e->ptr_full);
   else
     hipLaunchKernelGGL((k_update_deep<kC, false>), dim3(n_slabs * n_grp), dim3(kDeepThreads), lds, e->stream, e->T, e->sh.lda, e->colp, e->pass,
                        e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->st, e->steps, e->sh, e->is_basic, e->basis,
-                       n_slabs);
+                       n_slabs, e->ptr_full);
 }
 bool launch_update_deep(lpamd_engine* e) {
   switch (e->deep_batch) {
@@ -630,7 +631,8 @@ int enqueue_chain_update(lpamd_engine* e) {
     HIP_TRY(hipEventRecord(e0, e->stream));
   }
   hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + 255) / 256)), dim3(256), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
-                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->deep_batch);
+                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->deep_batch, e->T,
+                     e->ptr_full);
   LP_TRY(check_launch("k_chain_list"));
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
   const int grid = e->update_grid;
@@ -836,13 +838,14 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
   // Longer columns: a pivot is bound by the HBM pass, so a chain of pivots shares one (see k_update_chain)
   // (column shards chain through lpamd_chain_step, the caller runs the exchange of every step)
-  // Depth: 16 steps still hide under the HBM time of the pass (k_update_slab, col' in registers).  Beyond that the
-  // pass is bound by the fp64 vector rate (two instructions per entry and step plus the magnitude tracking) and
-  // grows by 0.18 ms per step at m=32768 n=65536 while a step's set-up costs 0.03 ms: 24 steps (k_update_deep,
-  // 6.35 ms per pass against 5.65) give 3400 pivots/s against 2630, 32 steps 3600 at 8 ms per pass.  Shards that
-  // fit the Infinity Cache are bound by the set-up launches and stay at 16.
+  // Depth: 16 steps still hide under the HBM time of the pass (k_update_slab, col' in registers).  Beyond about 20
+  // the fp64 vector rate (two instructions per entry and step plus the magnitude tracking) shows and the pass
+  // grows by 0.09 .. 0.18 ms per step at m=32768 n=65536 while a step's set-up costs 0.03 ms: 23 steps
+  // (k_update_deep, 5.97 ms per pass against 5.65, still 0.72 of the HBM peak) give 3450 pivots/s against 2600,
+  // 32 steps 3730 at 7.6 ms per pass (0.57 of the peak).  Shards that fit the Infinity Cache are bound by the
+  // set-up launches and stay at 16.
   const bool hbm_sized = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
-  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 24 : 16);
+  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 23 : 16);
   if (const char* env = getenv("LPAMD_CHAIN")) {
     e->chain_depth = std::max(1, std::min(kMaxChain, atoi(env)));
     if (e->chain_depth > 1) e->two_launch = false;
@@ -910,6 +913,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->list_part, sizeof(int32_t) * e->ncl));
     HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)(e->ncl + 8) * e->chain_depth));   // whole batches of up to 8 columns
     HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->chain_depth));
+    HIP_TRY(hipMalloc(&e->ptr_full, sizeof(uint64_t) * (size_t)(e->ncl + 8)));
   }
   HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * e->sh.lda, e->stream));    // rows beyond m stay zero
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
@@ -936,7 +940,7 @@ int lpamd_destroy(lpamd_engine* e) {
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part,
+  void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->ptr_full,
                   e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_rowbuf, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);

@@ -572,6 +572,26 @@ template <bool kNT> __device__ __forceinline__ void st16(double2* p, double2 v) 
     *p = v;
   }
 }
+// The same accesses through an address kept as an integer (a table of column addresses read with scalar loads):
+// the pointer is rebuilt in the global address space, so that the access is a global one (a flat access would count
+// against the LDS / scalar-load counter as well and every wait for an LDS read would wait for it) with the uniform
+// base in scalar registers and the lane's index as the offset.
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <bool kNT> __device__ __forceinline__ double2 ld16g(uint64_t base, uint32_t idx) {
+  const __attribute__((address_space(1))) d2v* p = (const __attribute__((address_space(1))) d2v*)base;
+  const d2v v = kNT ? __builtin_nontemporal_load(p + idx) : p[idx];
+  double2 o;
+  o.x = v.x;
+  o.y = v.y;
+  return o;
+}
+template <bool kNT> __device__ __forceinline__ void st16g(uint64_t base, uint32_t idx, double2 v) {
+  __attribute__((address_space(1))) d2v* p = (__attribute__((address_space(1))) d2v*)base;
+  d2v w;
+  w.x = v.x;
+  w.y = v.y;
+  if (kNT) __builtin_nontemporal_store(w, p + idx); else p[idx] = w;
+}
 __device__ __forceinline__ double2 rank1(double2 t, double2 c, double rj) {
   double2 o;
   o.x = flushz(__dadd_rn(t.x, __dmul_rn(c.x, rj)));
@@ -883,12 +903,12 @@ __device__ __forceinline__ int64_t deep_run_index(int k, int s, int depth, int c
 // that some step leaves alone (list_part: entering and leaving columns of the chain, mostly), and
 // the row' values of every listed column side by side (rsl_*[k * stride + s] = row'_s of the k-th
 // listed column, zero beyond the chain), which the pass reads as one short run per column.  batch > 0: list_full's
-// runs in the layout of deep_run_index instead.
+// runs in the layout of deep_run_index instead, and the address of every column of list_full in ptr_full.
 __global__ __launch_bounds__(256) void k_chain_list(
     const double* __restrict__ rowp, int64_t rstride, int depth, const ChainStep* __restrict__ steps,
     const PivotState* __restrict__ st, int ncl, PassInfo* __restrict__ pass,
     int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride,
-    int batch) {
+    int batch, Tab T, uint64_t* __restrict__ ptr_full) {
   if (st->status != ST_RUNNING) return;
   int n_steps = 1;
   while (n_steps < depth && steps[n_steps].done) n_steps++;
@@ -917,6 +937,7 @@ __global__ __launch_bounds__(256) void k_chain_list(
     (full ? list_full : list_part)[k] = l;
     if (full && batch > 0) {   // batches of `batch` columns, the values of one step side by side (k_update_deep)
       for (int s = 0; s < stride; s++) rsl_full[deep_run_index(k, s, stride, batch)] = s < n_steps ? rowp[s * rstride + l] : 0.0;
+      ptr_full[k] = (uint64_t)T.col(l);   // the addresses of a batch's columns: one scalar load in the pass
     } else {
       double* __restrict__ out = (full ? rsl_full : rsl_part) + (int64_t)k * stride;
       for (int s = 0; s < stride; s++) out[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
@@ -1134,12 +1155,12 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
 // is tracked, and a column that saw one is redone from memory with the drop in place.
 constexpr int kDeepThreads = 512;
 template <int kC, bool kNT>
-__global__ __launch_bounds__(kDeepThreads, 2) void k_update_deep(
+__global__ __launch_bounds__(kDeepThreads, kC == 4 ? 4 : 2) void k_update_deep(
     Tab T, int64_t lda, const double* __restrict__ colp, const PassInfo* __restrict__ passp,
     const int32_t* __restrict__ list_full, const int32_t* __restrict__ list_part,
     const double* __restrict__ rsl_full, const double* __restrict__ rsl_part, int depth,
     PivotState* __restrict__ st, ChainStep* __restrict__ steps, Shape sh,
-    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis, int n_slabs) {
+    uint8_t* __restrict__ is_basic, int64_t* __restrict__ basis, int n_slabs, const uint64_t* __restrict__ ptr_full) {
   extern __shared__ double2 s_c[];   // [n_steps][kWave]
   if (st->status != ST_RUNNING) return;
   const PassInfo pass = *passp;
@@ -1150,73 +1171,99 @@ __global__ __launch_bounds__(kDeepThreads, 2) void k_update_deep(
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int n_vec = (int)(lda / 2);
-  const int v0 = slab * kWave + lane;
+  const uint32_t v0 = (uint32_t)(slab * kWave + lane);
   const double2* __restrict__ cp = reinterpret_cast<const double2*>(colp);
   for (int q = threadIdx.x; q < n_steps * kWave; q += kDeepThreads)
     s_c[q] = cp[(int64_t)(q / kWave) * n_vec + slab * kWave + (q % kWave)];
   __syncthreads();
   constexpr int kWaves = kDeepThreads / kWave;
   const int stream = grp * kWaves + wave, n_streams = n_grp * kWaves;   // this wavefront: batches stream, stream + n_streams, ...
-  auto column = [&](int k) { return reinterpret_cast<double2*>(T.col(list_full[k])) + v0; };
   const int n_batches = n_steps == depth ? pass.n_full / kC : 0;
-  int b = stream;
-  if (b < n_batches) {
-    double2 t[kC];
+  // The addresses of a batch's columns are one scalar load (ptr_full, left by k_chain_list) and the lane's offset is
+  // added by the memory instruction itself.
+  auto load_batch = [&](int bb, double2 (&dst)[kC]) {
+    const uint64_t* __restrict__ pp = ptr_full + (int64_t)bb * kC;
 #pragma unroll
-    for (int u = 0; u < kC; u++) t[u] = ld16<kNT>(column(b * kC + u));
-    for (; b < n_batches; b += n_streams) {
-      // the same loads every round (the last one fetches its own batch again, unused): a load under a condition
-      // would make the compiler wait for all outstanding loads before the first use of the current batch
-      const int bn = b + n_streams < n_batches ? b + n_streams : b;
-      double2 tn[kC];
+    for (int u = 0; u < kC; u++) dst[u] = ld16g<kNT>(pp[u], v0);
+  };
+  // The chain on one batch held in t, then its stores.
+  auto work = [&](int bb, double2 (&t)[kC]) {
+    const double* __restrict__ rb = rsl_full + (int64_t)bb * depth * kC;
+    float low[kC];
 #pragma unroll
-      for (int u = 0; u < kC; u++) tn[u] = ld16<kNT>(column(bn * kC + u));
-      const double* __restrict__ rb = rsl_full + (int64_t)b * depth * kC;
-      float low[kC];
+    for (int u = 0; u < kC; u++) low[u] = FLT_MAX;
+    // The operands of a step (col'_s of the rows: one LDS read; the kC row' values: one scalar load) are requested
+    // one step ahead into a second set of registers, and only AFTER the current step has laid hands on its own
+    // set: scalar loads return out of order, so every wait for one is a wait for all outstanding, and
+    // a request issued before that wait would be waited for on the spot.
+    auto step = [&](const double2& cs, const double (&rj)[kC], double2& cs_ahead, double (&rj_ahead)[kC], int s_ahead) {
+      asm volatile("" : : "v"(cs.x), "s"(rj[kC - 1]));   // the current set has arrived (a use the compiler cannot move)
+      __builtin_amdgcn_sched_barrier(0);
+      cs_ahead = s_c[s_ahead * kWave + lane];
 #pragma unroll
-      for (int u = 0; u < kC; u++) low[u] = FLT_MAX;
-      // The operands of a step (col'_s of the rows: one LDS read; the kC row' values: one scalar load) are requested
-      // one step ahead into a second set of registers, and only AFTER the current step has laid hands on its own
-      // set: scalar loads return out of order, so every wait for one is a wait for all outstanding, and
-      // a request issued before that wait would be waited for on the spot.
-      auto step = [&](const double2& cs, const double (&rj)[kC], double2& cs_ahead, double (&rj_ahead)[kC], int s_ahead) {
-        asm volatile("" : : "v"(cs.x), "s"(rj[kC - 1]));   // the current set has arrived (a use the compiler cannot move)
-        __builtin_amdgcn_sched_barrier(0);
-        cs_ahead = s_c[s_ahead * kWave + lane];
-#pragma unroll
-        for (int u = 0; u < kC; u++) rj_ahead[u] = rb[s_ahead * kC + u];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kC; u++) {
-          const double px = __dmul_rn(cs.x, rj[u]), py = __dmul_rn(cs.y, rj[u]);
-          low[u] = min_magnitude_high(low[u], t[u].x, t[u].y);   // what the step before left (a stored entry is 0 or large)
-          t[u].x = __dadd_rn(t[u].x, px);
-          t[u].y = __dadd_rn(t[u].y, py);
-        }
-      };
-      double2 cs_a = s_c[lane], cs_b;
-      double rj_a[kC], rj_b[kC];
-#pragma unroll
-      for (int u = 0; u < kC; u++) rj_a[u] = rb[u];
-      int s = 0;
-      for (; s + 2 <= depth; s += 2) {
-        step(cs_a, rj_a, cs_b, rj_b, s + 1);
-        step(cs_b, rj_b, cs_a, rj_a, s + 2 < depth ? s + 2 : s + 1);
-      }
-      if (s < depth) step(cs_a, rj_a, cs_b, rj_b, s);
+      for (int u = 0; u < kC; u++) rj_ahead[u] = rb[s_ahead * kC + u];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int u = 0; u < kC; u++) {
-        low[u] = min_magnitude_high(low[u], t[u].x, t[u].y);
-        double2* __restrict__ p = column(b * kC + u);
-        if (__any(__float_as_uint(low[u]) <= kDropHigh)) {   // this column again, with the drop
-          double2 w = ld16<kNT>(p);                           // not stored yet
-          for (int s = 0; s < depth; s++) w = rank1(w, s_c[s * kWave + lane], rb[s * kC + u]);
-          t[u] = w;
+        const double px = __dmul_rn(cs.x, rj[u]), py = __dmul_rn(cs.y, rj[u]);
+        low[u] = min_magnitude_high(low[u], t[u].x, t[u].y);   // what the step before left (a stored entry is 0 or large)
+        t[u].x = __dadd_rn(t[u].x, px);
+        t[u].y = __dadd_rn(t[u].y, py);
+      }
+    };
+    double2 cs_a = s_c[lane], cs_b;
+    double rj_a[kC], rj_b[kC];
+#pragma unroll
+    for (int u = 0; u < kC; u++) rj_a[u] = rb[u];
+    int s = 0;
+    for (; s + 2 <= depth; s += 2) {
+      step(cs_a, rj_a, cs_b, rj_b, s + 1);
+      step(cs_b, rj_b, cs_a, rj_a, s + 2 < depth ? s + 2 : s + 1);
+    }
+    if (s < depth) step(cs_a, rj_a, cs_b, rj_b, s);
+    // Which columns saw a magnitude below the threshold: a scalar mask.  In the usual case (none) the stores follow
+    // without a single load between them; a load under a condition in front of a store would make the compiler
+    // wait for every outstanding memory operation, the store before included, at each of the kC stores.
+    uint32_t redo = 0;
+#pragma unroll
+    for (int u = 0; u < kC; u++) {
+      low[u] = min_magnitude_high(low[u], t[u].x, t[u].y);
+      if (__any(__float_as_uint(low[u]) <= kDropHigh)) redo |= 1u << u;
+    }
+    const uint64_t* __restrict__ pp = ptr_full + (int64_t)bb * kC;
+    if (redo == 0) {
+#pragma unroll
+      for (int u = 0; u < kC; u++) st16g<kNT>(pp[u], v0, t[u]);
+    } else {
+#pragma unroll 1
+      for (int u = 0; u < kC; u++) {
+        if ((redo >> u) & 1u) {                               // this column again, with the drop
+          double2 w = ld16g<kNT>(pp[u], v0);                  // not stored yet
+          for (int q = 0; q < depth; q++) w = rank1(w, s_c[q * kWave + lane], rb[q * kC + u]);
+          st16g<kNT>(pp[u], v0, w);
         }
-        st16<kNT>(p, t[u]);
       }
 #pragma unroll
-      for (int u = 0; u < kC; u++) t[u] = tn[u];
+      for (int u = 0; u < kC; u++)
+        if (!((redo >> u) & 1u)) st16g<kNT>(pp[u], v0, t[u]);
+    }
+  };
+  // Two register sets take turns (the loop is unrolled twice): while one is worked on, the loads of the next batch
+  // fill the other.  The same loads every round (the last one fetches its own batch again, unused): a load under a
+  // condition would make the compiler wait for all outstanding loads before the first use of the current batch.
+  int b = stream;
+  if (b < n_batches) {
+    double2 ta[kC], tb[kC];
+    load_batch(b, ta);
+    for (;;) {
+      load_batch(b + n_streams < n_batches ? b + n_streams : b, tb);
+      work(b, ta);
+      b += n_streams;
+      if (b >= n_batches) break;
+      load_batch(b + n_streams < n_batches ? b + n_streams : b, ta);
+      work(b, tb);
+      b += n_streams;
+      if (b >= n_batches) break;
     }
   }
   // step by step: what is left of list_full (all of it when the chain ended early), then list_part
