@@ -86,7 +86,6 @@ struct lpamd_engine {
   bool prb_use_cache = true;
   double* prb_v = nullptr;       // [3 * kMaxPartials] partials: smallest right-hand sides, largest bounds
   int64_t* prb_i = nullptr;      // [3 * kMaxPartials]
-  PrbRows* prb_rowbuf = nullptr; // rows that met the threshold of the row selection
   double* prb_ep_v = nullptr;    // [kPrbSliced * kPrbSlices] ratio partials of a short list evaluated in slices
   int64_t* prb_ep_i = nullptr;
   int32_t prb_rows = kPrbRows;   // rows the bounds are taken from
@@ -518,25 +517,17 @@ int enqueue_chain_step(lpamd_engine* e, int j, const Candidate* xcand, double* x
 
 int enqueue_chain_update(lpamd_engine* e);
 
-// MAX_REDUCTION pricing of step j of a pass from bounds (six small launches, no pass over the tableau): the
+// MAX_REDUCTION pricing of step j of a pass from bounds (seven small launches, no pass over the tableau): the
 // candidate record (column, row, score) lands in `cand`.
 int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_step = true) {
-  const int n_seg = (int)std::min<int64_t>(kPrbSegments, e->sh.m);   // segments of the rows whose minima give the threshold
-  double* sm_v = e->prb_v;
   double* pv = e->prb_v + kMaxPartials;
   int64_t* pi = e->prb_i + kMaxPartials;
   int64_t* pf = e->prb_i + 2 * kMaxPartials;
   double* rv = e->part_v + kMaxPartials;
   int64_t* ri = e->part_i + kMaxPartials;
-  hipLaunchKernelGGL(k_prb_small_rows, dim3(n_seg), dim3(kWave), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->rhs_next, sm_v,
-                     e->prb_rowbuf);
-  LP_TRY(check_launch("k_prb_small_rows"));
-  hipLaunchKernelGGL(k_prb_collect_rows, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->rhs_next,
-                     sm_v, n_seg, e->prb_rows, e->prb_rowbuf);
-  LP_TRY(check_launch("k_prb_collect_rows"));
-  hipLaunchKernelGGL(k_prb_pick_rows, dim3(1), dim3(kWave), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next, e->colp,
-                     e->prb_rowbuf, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
-  LP_TRY(check_launch("k_prb_pick_rows"));
+  hipLaunchKernelGGL(k_prb_rows, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next, e->colp,
+                     e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
+  LP_TRY(check_launch("k_prb_rows"));
   const bool cached = e->prb_use_cache;
   if (cached) {
     hipLaunchKernelGGL(k_prb_fill, dim3((unsigned)((e->sh.nloc + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0, e->stream, e->T,
@@ -894,8 +885,6 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->prb_cache, sizeof(double) * kPrbRows * (size_t)std::max<int64_t>(1, e->sh.nloc)));
     HIP_TRY(hipMalloc(&e->prb_v, sizeof(double) * 3 * kMaxPartials));
     HIP_TRY(hipMalloc(&e->prb_i, sizeof(int64_t) * 3 * kMaxPartials));
-    HIP_TRY(hipMalloc(&e->prb_rowbuf, sizeof(PrbRows)));
-    HIP_TRY(hipMemsetAsync(e->prb_rowbuf, 0, sizeof(PrbRows), e->stream));
     HIP_TRY(hipMalloc(&e->prb_ep_v, sizeof(double) * kPrbSliced * kPrbSlices));
     HIP_TRY(hipMalloc(&e->prb_ep_i, sizeof(int64_t) * kPrbSliced * kPrbSlices));
     if (const char* env = getenv("LPAMD_PRB_ROWS")) e->prb_rows = std::max(1, std::min(kPrbRows, atoi(env)));
@@ -941,7 +930,7 @@ int lpamd_destroy(lpamd_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
   void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->ptr_full,
-                  e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_rowbuf, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
+                  e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);

@@ -58,178 +58,163 @@ __device__ __forceinline__ const double* prb_rhs(const Tab& T, const Shape& sh, 
   return j == 0 ? T.col(sh.nloc) : rhsv + (int64_t)(j - 1) * sh.lda;
 }
 
-// The rows of R.  Exactly the rows with the smallest right-hand side matter (a row of rank 3 that is missed
-// costs a full evaluation of thousands of columns when it holds the minimum of the column with the largest
-// bound), so the selection is exact: (a) the minimum of every segment of the rows; (b) the
-// kPrbRows-th smallest of those minima is a threshold that at least kPrbRows rows meet, and hardly more:
-// all rows that meet it are collected; (c) one wavefront takes the smallest of the collected rows.
-// With (a) over 128 segments of the rows the threshold is met by about 40 rows.
-constexpr int kPrbCollect = 512;   // rows (c) can hold; more than that met the threshold only for short columns
-
-struct PrbRows {
-  int32_t n_collected;
-  int32_t pad;
-  int32_t row[kPrbCollect];
-  double b[kPrbCollect];
-};
-
-// 1a. smallest right-hand side of each of gridDim.x segments of the rows (one wavefront per segment)
+// 1. The rows of R, in one launch of a single workgroup.  Exactly the rows with the smallest right-hand side
+// matter (a row of rank 3 that is missed costs a full evaluation of thousands of columns when it holds the minimum
+// of the column with the largest bound), so the selection is exact: (a) the minimum of every one of 128 segments of
+// the rows; (b) the kPrbRows-th smallest of those minima is a threshold that at least kPrbRows rows meet, and
+// hardly more (about 40): all rows that meet it are collected in LDS; (c) the rows of the latest pivots come first
+// (a pivot scales its row by 1 / |pivot element|, and a row of large entries holds the minimum ratio of many
+// columns without having a small right-hand side), then the collected rows in the order of their right-hand side
+// (lowest row first on equal values) until R is full.  The right-hand side is m doubles that sit in the L2: one
+// workgroup reads it twice in less time than the three dependent launches cost that used to share this work.
+// The kernel also settles the budget at step 0, keeps the cache slots of the rows (see PrbInfo) and leaves the col'
+// entries of the steps so far at the rows of R in prb_c.
+constexpr int kPrbCollect = 512;   // rows (b) can hold; more than that met the threshold only for short columns
 constexpr int kPrbSegments = 128;
-__global__ __launch_bounds__(kWave) void k_prb_small_rows(
-    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
-    const double* __restrict__ rhsv, double* __restrict__ sm_v, PrbRows* __restrict__ rows) {
-  if (!prb_step_alive(st, steps, j)) return;
-  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
-  const int64_t seg = (sh.m + gridDim.x - 1) / gridDim.x;
-  const int64_t i1 = min((int64_t)(blockIdx.x + 1) * seg, sh.m);
-  double bv = DBL_MAX;
-  for (int64_t i = (int64_t)blockIdx.x * seg + threadIdx.x; i < i1; i += kWave) bv = fmin(bv, rhs[i]);
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) bv = fmin(bv, __shfl_xor(bv, off, kWave));
-  if (threadIdx.x == 0) sm_v[blockIdx.x] = bv;
-  if (blockIdx.x == 0 && threadIdx.x == 0) rows->n_collected = 0;
-}
-
-// 1b. every workgroup ranks the minima (n <= kPrbSegments of them, in LDS) to find the threshold, the `want`-th
-// smallest, and appends its rows that meet it.  (Finding the threshold once, in the workgroup of 1a that
-// finishes last, needs a device-wide fence, which costs more on this chip than ranking the values again.)
-__global__ __launch_bounds__(kPartialThreads) void k_prb_collect_rows(
-    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
-    const double* __restrict__ rhsv, const double* __restrict__ sm_v, int n, int want, PrbRows* __restrict__ rows) {
-  __shared__ double s_all[kPrbSegments];
+constexpr int kPrbRowThreads = 1024;
+__global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
+    Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
+    const double* __restrict__ rhsv, const double* __restrict__ colp, int max_rows,
+    const int64_t* __restrict__ trace, int64_t trace_cap, PrbInfo* __restrict__ info, double* __restrict__ prb_c) {
+  __shared__ double s_seg[kPrbSegments];
   __shared__ double s_tau;
-  if (!prb_step_alive(st, steps, j)) return;
-  for (int k = threadIdx.x; k < n; k += kPartialThreads) s_all[k] = sm_v[k];
-  if (threadIdx.x == 0) s_tau = DBL_MAX;          // fewer minima than rows wanted: every row qualifies
+  __shared__ int s_go, s_ncoll, s_nrecent, s_nfresh;
+  __shared__ int32_t s_crow[kPrbCollect];
+  __shared__ double s_cb[kPrbCollect];
+  __shared__ uint8_t s_fresh[kPrbCollect];
+  __shared__ int32_t s_R[kPrbRows];
+  __shared__ int32_t s_slot_row[kPrbRows], s_slot_jf[kPrbRows];
+  __shared__ int64_t s_recent[kPrbRecent];
+  const int tid = threadIdx.x;
+  // everything this kernel reads before it can start, requested by different threads at once (one round trip)
+  if (tid < kPrbRecent) {
+    const int64_t tq = st->iter - 1 - tid;
+    s_recent[tid] = (tq >= 0 && tq < trace_cap) ? trace[2 * tq + 1] : -1;
+  } else if (tid >= kWave && tid < kWave + kPrbRows) {
+    const int q = tid - kWave;
+    s_slot_row[q] = j == 0 ? -1 : info->slot_row[q];
+    s_slot_jf[q] = info->slot_jf[q];
+  } else if (tid == 2 * kWave) {
+    int go = 1;
+    if (st->status != ST_RUNNING) {
+      go = 0;
+    } else {
+      // the step records of the pass before are cleared even when the budget ends with step 0 (k_chain_list counts them)
+      if (j == 1) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
+      if (j == 0 && st->iter >= st->max_iter) { st->status = ST_LIMIT; go = 0; }   // as k_pr_fold does
+      else if (!prb_step_alive(st, steps, j)) go = 0;
+    }
+    s_go = go;
+    s_ncoll = 0;
+    s_nfresh = 0;
+    s_tau = DBL_MAX;            // fewer minima than rows wanted: every row qualifies
+  }
   __syncthreads();
-  for (int k = threadIdx.x; k < n; k += kPartialThreads) {
-    const double mine = s_all[k];
+  if (!s_go) return;
+  if (tid == 0) {               // the rows of the latest pivots, the latest first, each once
+    int n_recent = 0;
+    for (int q = 0; q < kPrbRecent && n_recent < max_rows; q++) {
+      const int64_t row = s_recent[q];
+      if (row < 0) break;
+      bool dup = false;
+      for (int k = 0; k < n_recent; k++) dup = dup || s_R[k] == (int32_t)row;
+      if (!dup) s_R[n_recent++] = (int32_t)row;
+    }
+    s_nrecent = n_recent;
+  }
+  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
+  // (a) eight threads per segment, all loads of a thread in flight together
+  const int n_seg = (int)min((int64_t)kPrbSegments, sh.m);
+  const int64_t seg = (sh.m + n_seg - 1) / n_seg;
+  constexpr int kPerSeg = kPrbRowThreads / kPrbSegments;
+  constexpr int kLoads = 16;   // loads in flight per thread (unconditional: the index is clamped, the value masked)
+  {
+    const int sidx = tid / kPerSeg, sub = tid % kPerSeg;
+    double bv = DBL_MAX;
+    if (sidx < n_seg) {
+      const int64_t i1 = min((int64_t)(sidx + 1) * seg, sh.m);
+      for (int64_t i = (int64_t)sidx * seg + sub; i < i1; i += kPerSeg * kLoads) {
+        double v[kLoads];
+#pragma unroll
+        for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPerSeg, i1 - 1)];   // a row read twice does not change a minimum
+#pragma unroll
+        for (int u = 0; u < kLoads; u++) bv = fmin(bv, v[u]);
+      }
+    }
+#pragma unroll
+    for (int off = kPerSeg / 2; off > 0; off >>= 1) bv = fmin(bv, __shfl_xor(bv, off, kWave));
+    if (sub == 0 && sidx < n_seg) s_seg[sidx] = bv;
+  }
+  __syncthreads();
+  // (b) the threshold, then the rows that meet it
+  if (tid < n_seg) {
+    const double mine = s_seg[tid];
     int rank = 0;
-    for (int q = 0; q < n; q++) rank += (s_all[q] < mine || (s_all[q] == mine && q < k)) ? 1 : 0;
-    if (rank == want - 1) s_tau = mine;
+#pragma unroll 16
+    for (int q = 0; q < n_seg; q++) {
+      const double other = s_seg[q];
+      rank += (other < mine || (other == mine && q < tid)) ? 1 : 0;
+    }
+    if (rank == max_rows - 1) s_tau = mine;
   }
   __syncthreads();
   const double tau = s_tau;
-  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
-  for (int64_t i0 = (int64_t)blockIdx.x * kPartialThreads; i0 < sh.m; i0 += (int64_t)gridDim.x * kPartialThreads) {
-    const int64_t i = i0 + threadIdx.x;
-    const double b = i < sh.m ? rhs[i] : 0.0;
-    const bool take = i < sh.m && b <= tau;
-    const unsigned long long mask = __ballot(take);
-    if (mask) {
-      const int lane = threadIdx.x & (kWave - 1);
-      int base = 0;
-      if (lane == 0) base = atomicAdd(&rows->n_collected, __popcll(mask));
-      base = __shfl(base, 0, kWave);
-      const int k = base + __popcll(mask & ((1ull << lane) - 1ull));
-      if (take && k < kPrbCollect) { rows->row[k] = (int32_t)i; rows->b[k] = b; }
-    }
-  }
-}
-
-// true on every lane whose `row` equals one of the rows the first n lanes hold in `held`
-__device__ __forceinline__ bool __any_dup(int64_t row, int64_t held, int n, int lane) {
-  bool dup = false;
-  for (int q = 0; q < n; q++) dup = dup || __shfl(held, q, kWave) == row;
-  (void)lane;
-  return dup;
-}
-
-// 1c. R: the rows of the latest pivots, then the smallest of the collected rows (lowest row on equal
-// right-hand sides), with the right-hand side and the col' entries of the steps so far at those rows.
-__global__ __launch_bounds__(kWave) void k_prb_pick_rows(
-    Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
-    const double* __restrict__ rhsv, const double* __restrict__ colp, const PrbRows* __restrict__ rows, int max_rows,
-    const int64_t* __restrict__ trace, int64_t trace_cap, PrbInfo* __restrict__ info, double* __restrict__ prb_c) {
-  if (st->status != ST_RUNNING) return;
-  const int lane = threadIdx.x;
-  // the step records of the pass before are cleared even when the budget ends with step 0 (k_chain_list counts them)
-  if (j == 1 && lane == 0) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
-  if (j == 0 && st->iter >= st->max_iter) { if (lane == 0) st->status = ST_LIMIT; return; }   // as k_pr_fold does
-  if (!prb_step_alive(st, steps, j)) return;
-  constexpr int kPer = kPrbCollect / kWave;
-  const int n_coll = min(rows->n_collected, kPrbCollect);
-  double v[kPer];
-  int64_t r[kPer];
+  for (int64_t i = tid; i < sh.m; i += kPrbRowThreads * kLoads) {
+    double v[kLoads];
 #pragma unroll
-  for (int q = 0; q < kPer; q++) {
-    const int k = lane + q * kWave;
-    v[q] = k < n_coll ? rows->b[k] : DBL_MAX;
-    r[q] = k < n_coll ? rows->row[k] : -1;
-  }
-  const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
-  // The rows of the latest pivots come first: a pivot scales its row by 1 / |pivot element|, and a row of
-  // large entries holds the minimum ratio of many columns without having a small right-hand side.
-  int n_rows = 0;
-  int64_t mine = -1;       // lane k keeps row k of R
-  const int64_t it = st->iter;
-  const int64_t tq = it - 1 - lane;
-  const int64_t recent = (lane < kPrbRecent && tq >= 0 && tq < trace_cap) ? trace[2 * tq + 1] : -1;   // all loads at once
-  for (int q = 0; q < kPrbRecent && n_rows < max_rows; q++) {
-    const int64_t row = __shfl(recent, q, kWave);
-    if (row < 0) break;
-    const bool dup = __any(lane < n_rows && mine == row);
-    if (dup) continue;
-    if (lane == n_rows) mine = row;
-    n_rows++;
-  }
-  // then the rows with the smallest right-hand side; the selection itself touches no memory
-  if (n_coll <= kWave) {
-    // the usual case, one collected row per lane: a row's rank among the rows that are not pivot rows already
-    const double mv = v[0];
-    const int64_t mr = r[0];
-    const bool fresh = !__any_dup(mr, mine, n_rows, lane) && mr >= 0;
-    int rank = 0;
-    for (int q = 0; q < n_coll; q++) {
-      const double ov = __shfl(mv, q, kWave);
-      const int64_t orow = __shfl(mr, q, kWave);
-      const bool ofresh = __shfl((int)fresh, q, kWave) != 0;
-      rank += (ofresh && (ov < mv || (ov == mv && orow < mr))) ? 1 : 0;
-    }
-    const bool take = fresh && rank < max_rows - n_rows;
-    const unsigned long long mask = __ballot(take);
-    const int pos = n_rows + __popcll(mask & ((1ull << lane) - 1ull));
-    // hand row `mr` of a taking lane to lane `pos`
-    for (int q = 0; q < kWave; q++) {
-      const bool tq = (mask >> q) & 1ull;
-      if (!tq) continue;
-      const int pq = n_rows + __popcll(mask & ((1ull << q) - 1ull));
-      const int64_t rq = __shfl(mr, q, kWave);
-      if (lane == pq) mine = rq;
-    }
-    (void)pos;
-    n_rows += __popcll(mask);
-  } else {
-    while (n_rows < max_rows) {
-      double bv = DBL_MAX;
-      int64_t bi = -1;
+    for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPrbRowThreads, sh.m - 1)];
 #pragma unroll
-      for (int q = 0; q < kPer; q++) take_min(bv, bi, v[q], r[q]);
-      wave_arg<false>(bv, bi);
-      bi = __shfl(bi, 0, kWave);
-      if (bi < 0) break;
-#pragma unroll
-      for (int q = 0; q < kPer; q++)
-        if (r[q] == bi) r[q] = -1;     // rows are distinct: exactly one lane drops it
-      if (__any(lane < n_rows && mine == bi)) continue;   // already in R as a pivot row
-      if (lane == n_rows) mine = bi;
-      n_rows++;
+    for (int u = 0; u < kLoads; u++) {
+      if (v[u] <= tau && i + u * kPrbRowThreads < sh.m) {
+        const int k = atomicAdd(&s_ncoll, 1);
+        if (k < kPrbCollect) { s_crow[k] = (int32_t)(i + u * kPrbRowThreads); s_cb[k] = v[u]; }
+      }
     }
   }
-  __shared__ int64_t s_rows[kPrbRows];
-  __shared__ int32_t s_slot_row[kPrbRows], s_slot_jf[kPrbRows];
-  if (lane < kPrbRows) { s_slot_row[lane] = j == 0 ? -1 : info->slot_row[lane]; s_slot_jf[lane] = info->slot_jf[lane]; }
-  if (lane < n_rows) { info->rows[lane] = (int32_t)mine; info->b[lane] = rhs[mine]; s_rows[lane] = mine; }
   __syncthreads();
+  // (c) the collected rows that are not pivot rows already, ranked by (right-hand side, row)
+  const int n_coll = min(s_ncoll, kPrbCollect), n_recent = s_nrecent;
+  if (tid < n_coll) {
+    bool fresh = true;
+    for (int k = 0; k < n_recent; k++) fresh = fresh && s_R[k] != s_crow[tid];
+    s_fresh[tid] = fresh ? 1 : 0;
+    if (fresh) atomicAdd(&s_nfresh, 1);
+  }
+  __syncthreads();
+  if (tid < n_coll && s_fresh[tid]) {
+    const double mv = s_cb[tid];
+    const int32_t mr = s_crow[tid];
+    int rank = 0;
+#pragma unroll 8
+    for (int q = 0; q < n_coll; q++) {
+      const double ob = s_cb[q];
+      const int32_t orow = s_crow[q];
+      const bool ofresh = s_fresh[q] != 0;
+      rank += (ofresh && (ob < mv || (ob == mv && orow < mr))) ? 1 : 0;
+    }
+    if (n_recent + rank < max_rows) s_R[n_recent + rank] = mr;
+  }
+  __syncthreads();
+  const int n_rows = min(max_rows, n_recent + s_nfresh);
+  for (int t = tid; t < n_rows * j; t += kPrbRowThreads) {     // independent loads, one or two per thread
+    const int k = t % n_rows, sidx = t / n_rows;
+    prb_c[sidx * kPrbRows + k] = colp[(int64_t)sidx * sh.lda + s_R[k]];
+  }
+  if (tid >= kWave) return;
+  // the first wavefront: lane k keeps row k of R
+  const int lane = tid;
+  const int64_t mine = lane < n_rows ? s_R[lane] : -1;
+  if (lane < n_rows) { info->rows[lane] = (int32_t)mine; info->b[lane] = rhs[mine]; }
   // cache slots: a row that a slot holds keeps it; the others take the slots no row of R occupies, lowest first
   int my_slot = -1;
   if (lane < n_rows)
     for (int q = 0; q < kPrbRows; q++)
       if (s_slot_row[q] == (int32_t)mine) my_slot = q;
   const bool hit = lane < n_rows && my_slot >= 0, miss = lane < n_rows && my_slot < 0;
+  const unsigned long long hits = __ballot(hit);
   unsigned used = 0;
-  for (int q = 0; q < kPrbRows; q++)
-    if (__any(hit && my_slot == q)) used |= 1u << q;
+  for (int q = 0; q < n_rows; q++)
+    if ((hits >> q) & 1ull) used |= 1u << __shfl(my_slot, q, kWave);
   const unsigned long long missing = __ballot(miss);
   const int nth = __popcll(missing & ((1ull << lane) - 1ull));
   if (miss) {
@@ -243,12 +228,10 @@ __global__ __launch_bounds__(kWave) void k_prb_pick_rows(
   }
   if (lane < n_rows) { info->slot[lane] = my_slot; info->jf[lane] = hit ? s_slot_jf[my_slot] : j; }
   if (j == 0 && lane < kPrbRows && lane >= n_rows) info->slot_row[lane] = -1;   // step 0 fills slots 0..n_rows-1
-  if (lane == 0) info->n_fill = __popcll(missing);
-  for (int t = lane; t < n_rows * j; t += kWave) {     // independent loads, a few per lane
-    const int k = t % n_rows, sidx = t / n_rows;
-    prb_c[sidx * kPrbRows + k] = colp[(int64_t)sidx * sh.lda + s_rows[k]];
+  if (lane == 0) {
+    info->n_fill = __popcll(missing);
+    info->n_rows = n_rows; info->n_list = 0; info->l1 = -1; info->first = -1; info->s1 = -DBL_MAX;
   }
-  if (lane == 0) { info->n_rows = n_rows; info->n_list = 0; info->l1 = -1; info->first = -1; info->s1 = -DBL_MAX; }
 }
 
 // basis flag of local column l after the pivots set up so far (the pass kernel flips is_basic[] later)
@@ -499,7 +482,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_eval(
 // 6. the reference's fold (lp_simplex_tableau.cc:310-325 / 353-362) over the exact results: largest score
 // among columns that have a row, lowest column on ties; no such column: the lowest candidate with row -1
 // (=> unbounded); no candidate: gcol -1 (=> optimal).  A later step of the chain records its entering
-// column for k_chain_finalize (step 0 hands the record to k_pivot_finalize; k_prb_pick_rows has settled the budget).
+// column for k_chain_finalize (step 0 hands the record to k_pivot_finalize; k_prb_rows has settled the budget).
 __global__ __launch_bounds__(kPartialThreads) void k_prb_pick(
     Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
     const double* __restrict__ obj, const PrbInfo* __restrict__ info, const int32_t* __restrict__ elist,
