@@ -1555,9 +1555,9 @@ int lpamd_lookahead_export(lpamd_engine* e, void* cand_dev, void* xlocal_dev) {
   CHECK_LOADED(e);
   if (!cand_dev || !xlocal_dev) return set_err(LPAMD_E_ARG, "lookahead_export: null buffer");
   if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
-  hipLaunchKernelGGL(k_export_lookahead, dim3((unsigned)((e->sh.lda + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0,
+  hipLaunchKernelGGL(k_export_lookahead<false>, dim3((unsigned)((e->sh.lda + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0,
                      e->stream, e->T, e->sh, e->st, e->part_v, e->part_i, e->n_price_part, (Candidate*)cand_dev, e->colp, e->rowp,
-                     e->rstride, e->steps, e->update_pending ? e->pending_steps : 0, (double*)xlocal_dev);
+                     e->rstride, e->steps, e->update_pending ? e->pending_steps : 0, (double*)xlocal_dev, nullptr, nullptr, nullptr);
   return check_launch("k_export_lookahead");
 }
 
@@ -1602,6 +1602,46 @@ int lpamd_chain_step(lpamd_engine* e, void* xbuf_dev) {
   e->pending_steps++;
   return LPAMD_OK;
 }
+
+}  // extern "C"
+
+namespace {
+
+// Ratio-test partials a slot carries behind the column: one (value, row) pair per 256 rows.
+int64_t slot_ratio_parts(const lpamd_engine* e) { return (e->sh.lda + kPartialThreads - 1) / kPartialThreads; }
+
+// Column shards, MAX_COST, a step inside a chain: this rank's candidate for the NEXT pivot packed into `slot` (record,
+// column as the pivots set up so far will leave it, ratio-test partials on that column).
+int export_lookahead_ratio(lpamd_engine* e, uint64_t* slot, int header_words) {
+  if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
+  const int64_t n_parts = slot_ratio_parts(e);
+  double* col = reinterpret_cast<double*>(slot + header_words);
+  double* rpv = col + e->sh.lda;
+  hipLaunchKernelGGL(k_export_lookahead<true>, dim3((unsigned)n_parts), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->part_v, e->part_i,
+                     e->n_price_part, reinterpret_cast<Candidate*>(slot), e->colp, e->rowp, e->rstride, e->steps,
+                     e->update_pending ? e->pending_steps : 0, col, e->rhs_next, rpv, reinterpret_cast<int64_t*>(rpv + n_parts));
+  return check_launch("k_export_lookahead");
+}
+
+// ... and the set-up of that pivot on every rank straight from the gathered slots (no fold kernel, no ratio-test launch).
+int chain_step_from_slots(lpamd_engine* e, const uint64_t* slots, int world, int64_t slot_words, int header_words) {
+  if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain step: no pivot has been set up by lpamd_lookahead_setup");
+  if (e->pending_steps >= e->chain_depth) return set_err(LPAMD_E_STATE, "chain step: the pass already holds %d pivots", e->pending_steps);
+  e->apply_since_pull++;
+  LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
+  hipLaunchKernelGGL((k_chain_finalize<true, false, true>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh,
+                     e->st, e->steps, e->pending_steps, nullptr, nullptr, (int)slot_ratio_parts(e), e->n_row_blocks, e->colp, e->rowp, e->rstride,
+                     e->rhs_next, nullptr, nullptr, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i, slots, world,
+                     slot_words, header_words, e->chain_depth);
+  LP_TRY(check_launch("k_chain_finalize"));
+  e->price_partials_fresh = true;
+  e->pending_steps++;
+  return LPAMD_OK;
+}
+
+}  // namespace
+
+extern "C" {
 
 int lpamd_lookahead_update(lpamd_engine* e) {
   CHECK_LOADED(e);

@@ -801,7 +801,13 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
 // kFindRow: the row comes from the ratio-test partials (MAX_COST); otherwise with the candidate
 // record `xcand` (MAX_REDUCTION prices column and row together).  kRebuild: the entering column is
 // a local column and is rebuilt here through the steps so far; otherwise it is given in `colv`.
-template <bool kFindRow, bool kRebuild>
+// kSlots (column shards, MAX_COST): the step is set up straight from the gathered exchange slots.  Every workgroup
+// folds the ranks' candidate records itself (largest reduced cost, lowest global column on ties; reference
+// lp_simplex_tableau.cc:188-198), takes the winner's column from the winner's slot and folds the ratio-test partials
+// its owner left there (k_export_lookahead<true>), which replaces the fold kernel and k_chain_ratio of that step.
+// The budget has been settled by the exporting kernel ("no candidate" once it is used up): this launch advances
+// the pivot count, so its workgroups cannot test it themselves.
+template <bool kFindRow, bool kRebuild, bool kSlots = false>
 __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j,
     const double* __restrict__ rv, const int64_t* __restrict__ ri, int n_ratio_part, int n_row_blocks,
@@ -809,13 +815,45 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     const Candidate* __restrict__ xcand,
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
     int64_t* __restrict__ trace, int64_t trace_cap,
-    double* __restrict__ next_pv, int64_t* __restrict__ next_pi) {
+    double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
+    const uint64_t* __restrict__ slots = nullptr, int slot_world = 0, int64_t slot_words = 0, int slot_header = 0, int depth = 0) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
+  __shared__ int s_w;
   if (st->status != ST_RUNNING) return;
+  const bool keeper = (int)blockIdx.x == n_row_blocks && threadIdx.x == 0;   // the thread that records the step
+  if (kSlots && j == 1 && keeper)   // the step records of the pass before (k_chain_ratio does this in the other loops)
+    for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
   if (j > 1 && !steps[j - 1].done) return;
-  const int64_t e2 = steps[j].e;
-  if (e2 < 0) return;
+  int64_t e2;
+  double ce2;
+  if (kSlots) {
+    if (threadIdx.x == 0) {
+      int w = -1;
+      double bk = 0.0;
+      int64_t bg = -1;
+      for (int k = 0; k < slot_world; k++) {
+        const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)k * slot_words);
+        if (c.gcol < 0) continue;
+        if (w < 0 || c.key > bk || (c.key == bk && c.gcol < bg)) { w = k; bk = c.key; bg = c.gcol; }
+      }
+      s_w = w;
+    }
+    __syncthreads();
+    const int w = s_w;
+    if (w < 0) return;                    // optimal after step j-1, or the budget ends with it
+    const uint64_t* __restrict__ mine = slots + (size_t)w * slot_words;
+    const Candidate c = *reinterpret_cast<const Candidate*>(mine);
+    e2 = c.gcol;
+    ce2 = c.ce;
+    colv = reinterpret_cast<const double*>(mine + slot_header);
+    rv = colv + sh.lda;                   // the owner's ratio-test partials: values, then rows
+    ri = reinterpret_cast<const int64_t*>(rv + n_ratio_part);
+  } else {
+    e2 = steps[j].e;
+    if (e2 < 0) return;
+    ce2 = steps[j].ce;
+  }
   int64_t r2;
   if (kFindRow) {
     double best;
@@ -832,7 +870,6 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   const int l_e2 = local_id(e2);
   if (kRebuild && l_e2 < 0) return;   // not reachable: a rebuilt column is a local one
   const double* __restrict__ ecol = kRebuild ? T.col(l_e2) : colv;
-  const double ce2 = steps[j].ce;
   const double a2 = kRebuild ? chain_apply(ecol[r2], j, colp + r2, sh.lda, rowp + l_e2, rstride) : colv[r2];
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
@@ -883,6 +920,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
   if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
   if (cb == 0 && threadIdx.x == 0) {
+    if (kSlots) { steps[j].e = e2; steps[j].ce = ce2; }
     steps[j].r = r2; steps[j].d = d2; steps[j].a = a2; steps[j].f = f2; steps[j].g = g2;
     steps[j].l_in = l_e2; steps[j].l_out = l_d2;
     steps[j].done = 1;
@@ -1336,16 +1374,24 @@ __global__ __launch_bounds__(256) void k_export_or_zero(
 // The local candidate is folded here from the pricing partials the last set-up left (every
 // workgroup folds them itself, workgroup 0 writes the 32-byte record), which saves the launch of
 // k_price_fold in front of every exchange.
+// kRatio: the workgroup also leaves the ratio-test partial of its rows (reference lp_simplex_tableau.cc:207-227: smallest
+// b_i / (-a_i) over (float)a_i <= -1e-6f, lowest row on ties) on that column and the right-hand side after the same steps, in
+// rpart_v / rpart_i behind the column, so that whoever receives the slot can fold the pivot row without a ratio-test
+// launch of its own; and a used-up budget travels as "no candidate" (the kernel that consumes the slots advances the
+// pivot count itself and cannot test it).
+template <bool kRatio>
 __global__ __launch_bounds__(kPartialThreads) void k_export_lookahead(
     Tab T, Shape sh, const PivotState* __restrict__ st, const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
     Candidate* __restrict__ cand_local, const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride,
-    const ChainStep* __restrict__ steps, int pending, double* __restrict__ xlocal) {
+    const ChainStep* __restrict__ steps, int pending, double* __restrict__ xlocal,
+    const double* __restrict__ rhsv, double* __restrict__ rpart_v, int64_t* __restrict__ rpart_i) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   double ce;
   int64_t l;
   fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
+  if (kRatio && st->iter >= st->max_iter) l = -1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     Candidate c;
     c.key = ce; c.ce = ce; c.row = -1;
@@ -1353,14 +1399,20 @@ __global__ __launch_bounds__(kPartialThreads) void k_export_lookahead(
     *cand_local = c;
   }
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= sh.lda) return;
+  if (!kRatio && i >= sh.lda) return;
   double v = 0.0;
-  if (l >= 0 && i < sh.m) {
-    int n = pending > 0 ? 1 : 0;
-    while (n > 0 && n < pending && steps[n].done) n++;
-    v = chain_apply(T.col(l)[i], n, colp + i, sh.lda, rowp + l, rstride);   // the update leaves columns with row' == 0 alone
+  int n = pending > 0 ? 1 : 0;
+  while (n > 0 && n < pending && steps[n].done) n++;
+  if (l >= 0 && i < sh.m) v = chain_apply(T.col(l)[i], n, colp + i, sh.lda, rowp + l, rstride);   // the update leaves columns with row' == 0 alone
+  if (i < sh.lda) xlocal[i] = v;
+  if (kRatio) {
+    const double* __restrict__ rhs = n == 0 ? T.col(sh.nloc) : rhsv + (int64_t)(n - 1) * sh.lda;
+    double bv = DBL_MAX;
+    int64_t bi = -1;
+    if (l >= 0 && i < sh.m && (float)v <= -1e-6f) { bv = rhs[i] / (-v); bi = i; }
+    block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+    if (threadIdx.x == 0) { rpart_v[blockIdx.x] = bv; rpart_i[blockIdx.x] = bi; }
   }
-  xlocal[i] = v;
 }
 
 // Runs on the exchange stream, next to the update: folds the gathered records (largest

@@ -198,7 +198,7 @@ struct lpamd_shard {   // one column shard of a group and its exchange state
   hipEvent_t ev_sent = nullptr, ev_arrived = nullptr;
   hipEvent_t ev_pub = nullptr, ev_read = nullptr;   // in-process exchange
   ncclComm_t comm = nullptr;
-  uint64_t* slot = nullptr;                  // kSlotHeaderWords + lda words: what this rank sends
+  uint64_t* slot = nullptr;                  // slot_words words (record, column, ratio-test partials): what this rank sends
   uint64_t* slots = nullptr;                 // world slots: what every rank receives
   double* xbuf = nullptr;                    // lda doubles: the entering column of the pivot being set up
   uint64_t* send = nullptr;                  // assembly of rows / columns / objective: max(N + 2, lda) words ...
@@ -214,6 +214,7 @@ struct lpamd_group {
   int engine_world = 1;           // shards the columns are dealt over (differs from world only in a rehearsal)
   bool local_exchange = false;
   bool inline_exchange = true;    // collectives inside a chain run on the engine's stream (nothing to overlap them with)
+  bool fused_step = true;         // MAX_COST steps inside a chain: ratio-test partials travel with the slot, two launches per step
   int chain = 1;                  // pivots per pass of the look-ahead loop
   int poll_every = 64;
   std::vector<lpamd_shard> shards;           // the shards this process holds
@@ -381,6 +382,12 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
       HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));
       LP_TRY(lpamd_lookahead_setup(e, s.xbuf));
       for (int j = 1; j < g->chain; j++) {
+        if (g->fused_step) {   // export with ratio-test partials, all-gather, set-up straight from the slots
+          LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));
+          LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
+          LP_TRY(chain_step_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords));
+          continue;
+        }
         LP_TRY(export_lookahead(s));
         LP_TRY(exchange_lookahead(g, s, !g->inline_exchange));
         if (!g->inline_exchange) HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));
@@ -642,12 +649,18 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   g->engine_world = world;
   g->lda = lpamd_exchange_bytes(m) / (int64_t)sizeof(double);
   if (const char* env = getenv("LPAMD_LDA_PAD")) g->lda += round_up(std::max(0, atoi(env)), kSlabRows);
-  g->slot_words = kSlotHeaderWords + g->lda;
+  g->slot_words = kSlotHeaderWords + g->lda + 2 * ((g->lda + kPartialThreads - 1) / kPartialThreads);   // record, column, ratio-test partials
   g->wide = std::max<int64_t>(N + 2, g->lda);
   g->local_exchange = (flags & LPAMD_GROUP_LOCAL_EXCHANGE) != 0;
   g->pub.assign(world, nullptr);
   if (const char* env = getenv("LPAMD_SHARD_INLINE")) g->inline_exchange = atoi(env) != 0;
+  // The in-process exchange enqueues 2 event records and `world` device copies per shard and pivot.  With 8 shards on
+  // one GPU and 64 pivots between two reads of the pivot state, that backlog was seen to exhaust something in the
+  // driver that every process on the machine needs (other processes' HSA start-up crashed until the backlog had
+  // drained); 16 pivots between reads keep it short.  RCCL exchanges enqueue one collective per pivot and keep 64.
+  if (g->local_exchange) g->poll_every = 16;
   if (const char* env = getenv("LPAMD_SHARD_POLL")) g->poll_every = std::max(1, atoi(env));
+  if (const char* env = getenv("LPAMD_SHARD_FUSED")) g->fused_step = atoi(env) != 0;
   return g;
 }
 
