@@ -828,7 +828,23 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   int64_t e2;
   double ce2;
   if (kSlots) {
-    if (threadIdx.x == 0) {
+    if (slot_world <= kWave) {          // one record per lane of the first wavefront: all loads at once
+      if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        double key = -DBL_MAX;
+        int64_t gc = -1;
+        if (lane < slot_world) {
+          const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)lane * slot_words);
+          if (c.gcol >= 0) { key = c.key; gc = c.gcol; }
+        }
+        double bk = key;
+        int64_t bg = gc;
+        wave_arg<true>(bk, bg);           // larger key, lower global column on ties
+        bg = __shfl(bg, 0, kWave);
+        const unsigned long long owner = __ballot(gc >= 0 && gc == bg);
+        if (lane == 0) s_w = bg < 0 ? -1 : __ffsll((long long)owner) - 1;
+      }
+    } else if (threadIdx.x == 0) {
       int w = -1;
       double bk = 0.0;
       int64_t bg = -1;
