@@ -525,8 +525,12 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_ste
   int64_t* pf = e->prb_i + 2 * kMaxPartials;
   double* rv = e->part_v + kMaxPartials;
   int64_t* ri = e->part_i + kMaxPartials;
-  hipLaunchKernelGGL(k_prb_rows, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next, e->colp,
-                     e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
+  if (e->sh.m <= 256 * kPrbSegments)
+    hipLaunchKernelGGL(k_prb_rows<true>, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next,
+                       e->colp, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
+  else
+    hipLaunchKernelGGL(k_prb_rows<false>, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next,
+                       e->colp, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
   LP_TRY(check_launch("k_prb_rows"));
   const bool cached = e->prb_use_cache;
   if (cached) {

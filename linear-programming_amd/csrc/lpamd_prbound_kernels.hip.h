@@ -72,6 +72,7 @@ __device__ __forceinline__ const double* prb_rhs(const Tab& T, const Shape& sh, 
 constexpr int kPrbCollect = 512;   // rows (b) can hold; more than that met the threshold only for short columns
 constexpr int kPrbSegments = 128;
 constexpr int kPrbRowThreads = 1024;
+template <bool kKeepRows>   // segments of at most 256 rows: see (a)
 __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
     const double* __restrict__ rhsv, const double* __restrict__ colp, int max_rows,
@@ -123,24 +124,37 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     s_nrecent = n_recent;
   }
   const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
-  // (a) eight threads per segment, all loads of a thread in flight together
+  // (a) eight threads per segment, all loads of a thread in flight together.  Up to 256 rows per segment (m <= 32768)
+  // a thread's 32 values stay in registers and the rows that meet the threshold are picked from them in (b); longer
+  // columns are read a second time.
   const int n_seg = (int)min((int64_t)kPrbSegments, sh.m);
   const int64_t seg = (sh.m + n_seg - 1) / n_seg;
   constexpr int kPerSeg = kPrbRowThreads / kPrbSegments;
-  constexpr int kLoads = 16;   // loads in flight per thread (unconditional: the index is clamped, the value masked)
-  {
-    const int sidx = tid / kPerSeg, sub = tid % kPerSeg;
-    double bv = DBL_MAX;
-    if (sidx < n_seg) {
-      const int64_t i1 = min((int64_t)(sidx + 1) * seg, sh.m);
-      for (int64_t i = (int64_t)sidx * seg + sub; i < i1; i += kPerSeg * kLoads) {
-        double v[kLoads];
+  constexpr int kKeep = 32;    // values a thread keeps
+  constexpr int kLoads = 16;   // loads in flight per thread otherwise (unconditional: the index is clamped, the value masked)
+  constexpr bool keep = kKeepRows;
+  const int sidx = tid / kPerSeg, sub = tid % kPerSeg;
+  const int64_t i0 = (int64_t)sidx * seg + sub, i1 = sidx < n_seg ? min((int64_t)(sidx + 1) * seg, sh.m) : 0;
+  double kept[kKeepRows ? kKeep : 1];
+  double mymin = DBL_MAX;
+  if constexpr (keep) {
+    if (i0 < i1) {
 #pragma unroll
-        for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPerSeg, i1 - 1)];   // a row read twice does not change a minimum
+      for (int u = 0; u < kKeep; u++) kept[u] = rhs[min(i0 + u * kPerSeg, i1 - 1)];   // a row read twice does not change a minimum
 #pragma unroll
-        for (int u = 0; u < kLoads; u++) bv = fmin(bv, v[u]);
-      }
+      for (int u = 0; u < kKeep; u++) mymin = fmin(mymin, kept[u]);
     }
+  } else if (sidx < n_seg) {
+    for (int64_t i = i0; i < i1; i += kPerSeg * kLoads) {
+      double v[kLoads];
+#pragma unroll
+      for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPerSeg, i1 - 1)];
+#pragma unroll
+      for (int u = 0; u < kLoads; u++) mymin = fmin(mymin, v[u]);
+    }
+  }
+  {
+    double bv = mymin;
 #pragma unroll
     for (int off = kPerSeg / 2; off > 0; off >>= 1) bv = fmin(bv, __shfl_xor(bv, off, kWave));
     if (sub == 0 && sidx < n_seg) s_seg[sidx] = bv;
@@ -159,15 +173,28 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
   }
   __syncthreads();
   const double tau = s_tau;
-  for (int64_t i = tid; i < sh.m; i += kPrbRowThreads * kLoads) {
-    double v[kLoads];
+  if constexpr (keep) {
+    if (mymin <= tau) {        // a few threads only
 #pragma unroll
-    for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPrbRowThreads, sh.m - 1)];
+      for (int u = 0; u < kKeep; u++) {
+        const int64_t i = i0 + u * kPerSeg;
+        if (i < i1 && kept[u] <= tau) {
+          const int k = atomicAdd(&s_ncoll, 1);
+          if (k < kPrbCollect) { s_crow[k] = (int32_t)i; s_cb[k] = kept[u]; }
+        }
+      }
+    }
+  } else {
+    for (int64_t i = tid; i < sh.m; i += kPrbRowThreads * kLoads) {
+      double v[kLoads];
 #pragma unroll
-    for (int u = 0; u < kLoads; u++) {
-      if (v[u] <= tau && i + u * kPrbRowThreads < sh.m) {
-        const int k = atomicAdd(&s_ncoll, 1);
-        if (k < kPrbCollect) { s_crow[k] = (int32_t)(i + u * kPrbRowThreads); s_cb[k] = v[u]; }
+      for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPrbRowThreads, sh.m - 1)];
+#pragma unroll
+      for (int u = 0; u < kLoads; u++) {
+        if (v[u] <= tau && i + u * kPrbRowThreads < sh.m) {
+          const int k = atomicAdd(&s_ncoll, 1);
+          if (k < kPrbCollect) { s_crow[k] = (int32_t)(i + u * kPrbRowThreads); s_cb[k] = v[u]; }
+        }
       }
     }
   }
