@@ -271,8 +271,8 @@ def main():
                      "fp64_vector": {"achieved_Tops": round(2.0 * m * touched_cols / secs / 1e12, 2) if passes else 0.0,
                                      "peak_Tops": FP64_VECTOR_PEAK_TOPS, "frac": round(2.0 * m * touched_cols / secs / 1e12 / FP64_VECTOR_PEAK_TOPS, 4) if passes else 0.0,
                                      "note": "separately rounded multiply + add per entry and chained pivot (no FMA: the reference rounds twice); "
-                                             "peak = 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz; beyond 16 pivots per pass this, "
-                                             "not HBM, bounds the pass (plus one v_min3_f32 per two entries and step for the 1e-6 drop)"},
+                                             "peak = 256 CUs x 4 SIMDs x 16 fp64 lanes per clock x 2.4 GHz; beyond about 20 pivots per pass this "
+                                             "resource shows in the pass time beside HBM (plus one v_min3_f32 per two entries and step for the 1e-6 drop)"},
                      "note": "achieved = HBM bytes one launch streams (16*m per column it reads and writes, once per pass) / its "
                              "duration (HIP events on the engine's stream); a launch applies pivots_per_pass pivots to every entry, "
                              "so the per-pivot algorithmic bytes (16*m*n_active per pivot) give algorithmic_GBps, which may exceed the "

@@ -1,20 +1,23 @@
 #!/bin/bash
 # Everything profiles/roundN/ holds, in one run on the GPU box (about 8 minutes):
 #   bash scripts/profile_round.sh && cp gpurun_out/prof_round/* profiles/roundN/
+# Prints a progress line per leg.
 set -e
 export TMPDIR=/tmp
 o=gpurun_out/prof_round
 rm -rf $o; mkdir -p $o
 stats() {   # stats <name> <bench args...>: rocprofv3 kernel stats of one bench command
   local name=$1; shift
+  echo "stats $name"
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/st_$name -- python3 bench.py --no-cpu-baseline "$@" > $o/${name}_under_rocprof.json 2>> $o/err.log
   find $o/st_$name -name "*kernel_stats.csv" -exec cp {} $o/${name}_kernel_stats.csv \;
   rm -rf $o/st_$name
 }
 pmc() {     # pmc <name> <bench args...>: the two PMC passes and their reduction
   local name=$1; shift
-  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
-  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 32 --warmup 16 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
+  echo "pmc $name"
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 46 --warmup 23 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 46 --warmup 23 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
   python3 scripts/pmc_traffic.py $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json > $o/pmc_hbm_traffic_$name.json
   rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json $o/pmc_write.json
 }
@@ -44,11 +47,28 @@ done
 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --strategy max_reduction --steps 256 --warmup 64 --no-cpu-baseline > $o/shard_of_8_max_reduction.json 2>> $o/err.log
 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --config synthetic_m65536_n262144 --strategy max_reduction --steps 64 --warmup 32 --no-cpu-baseline > $o/shard_of_8_m65536_n262144_max_reduction.json 2>> $o/err.log
 LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_cost --steps 512 --warmup 64
+# depth of the chain against the pass kernel (k_update_deep from 17 steps on; 16 and below: k_update_slab)
+for d in 12 16 18 20 22 23 24 26 28 32; do
+  LPAMD_CHAIN=$d timeout -k 10 200 python3 -u bench.py --steps $((d*6)) --warmup $d --no-cpu-baseline 2>> $o/err.log | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('depth $d', r['value'], 'pivots/s', r['roofline']['avg_launch_ms'], 'ms/pass', r['roofline']['achieved'], 'GB/s', r['roofline']['kernel'])
+" >> $o/sweep_depth_m32768_n65536.txt
+done
+for d in 16 23 32; do
+  LPAMD_CHAIN=$d timeout -k 10 200 python3 -u bench.py --strategy max_reduction --steps $((d*4)) --warmup $d --no-cpu-baseline 2>> $o/err.log | python3 -c "
+import json,sys
+r=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('max_reduction depth $d', r['value'], 'pivots/s', r['roofline']['avg_launch_ms'], 'ms/pass', r['roofline']['achieved'], 'GB/s')
+" >> $o/sweep_depth_m32768_n65536.txt
+done
+LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_reduction --strategy max_reduction --steps 256 --warmup 64
 python3 - <<'PY'
 import glob, json
 for f in sorted(glob.glob("gpurun_out/prof_round/*.json")):
     try:
-        d = json.loads([l for l in open(f).read().splitlines() if l.startswith("{")][-1])
+        text = open(f).read()
+        d = json.loads(text) if text.lstrip().startswith("{\n") else json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
     except Exception as ex:
         print(f, "unreadable", ex); continue
     if "metric" in d:
