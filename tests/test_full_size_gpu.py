@@ -219,3 +219,33 @@ def test_m32768_n65536_as_eight_shards(lpamd):
         assert np.array_equal(bits(engines[j % 8].read_column(j)), bits(one.read_column(j))), "column %d" % j
     g.close()
     one.close()
+
+
+def test_m65536_n262144_max_reduction_as_eight_shards(lpamd):
+    """BASELINE's largest configuration in its sharded form at its own size: 8 column shards of 21.5 GB each
+    (here on one GPU, in-process exchange) behind lpamd_group_*, max-reduction pricing from bounds with a chain
+    of pivots per pass, against the storage-free oracle: pivot sequence on every shard, right-hand-side
+    replicas, objective row and sampled columns bit for bit (reference lp_simplex_tableau.cc:235-374, 10-52)."""
+    m, n, seed, k = 65536, 262144, 1, 4
+    N = n + m
+    g = lpamd.ShardGroup(m, N, 8, devices=[0] * 8, local_exchange=True)
+    assert g.chain() > 1
+    g.fill_synthetic(n, seed)
+    for leg in (3, 1):                        # a pass of three chained pivots, then one more
+        assert g.run_pivots(lpamd.MAX_REDUCTION, leg) == (lpamd.LIMIT, leg)
+    st = lo.StreamedSynthetic(m, n, seed, kmax=k)
+    assert st.run(lo.MAX_REDUCTION, k) == lo.LIMIT
+    trace, obj, rhs, basic = st.state()
+    engines = [g.engine(q) for q in range(8)]
+    for q, eng in enumerate(engines):
+        assert eng.trace() == trace, "shard %d walked other pivots" % q
+        assert np.array_equal(bits(eng.read_column(N)), bits(rhs)), "RHS replica of shard %d differs from the oracle" % q
+    _, gobj, gbasic = g.download(tableau=False)
+    assert np.array_equal(bits(gobj[: N + 1]), bits(obj[: N + 1]))
+    assert np.array_equal(gbasic[:N], basic[:N])
+    for j in _sample_columns(np.random.default_rng(9), n, N, trace, 24):
+        if j == N:
+            continue
+        assert np.array_equal(bits(engines[j % 8].read_column(j)), bits(st.column(j))), "column %d" % j
+    st.close()
+    g.close()
