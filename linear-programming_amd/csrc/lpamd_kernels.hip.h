@@ -946,6 +946,16 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   }
 }
 
+// Steps 1..limit-1 of the pass that have been set up, counted from the front (step 0 lives in PivotState and always
+// exists): one lane per step record, so that the flags arrive in one round trip instead of one per step.
+__device__ __forceinline__ int chain_steps_done(const ChainStep* __restrict__ steps, int limit) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool done = lane == 0 || (lane < limit && steps[lane].done != 0);
+  const unsigned long long mask = __ballot(done);
+  const int n = __ffsll((long long)~mask) - 1;      // lanes beyond kMaxChain <= 32 are never done: a zero bit exists
+  return n < limit ? n : limit;
+}
+
 // Where row'_s of the k-th column of list_full lives when the runs are laid out for k_update_deep: the columns
 // in batches of c, inside a batch the c values of one step next to each other.
 __device__ __forceinline__ int64_t deep_run_index(int k, int s, int depth, int c) {
@@ -964,8 +974,7 @@ __global__ __launch_bounds__(256) void k_chain_list(
     int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride,
     int batch, Tab T, uint64_t* __restrict__ ptr_full) {
   if (st->status != ST_RUNNING) return;
-  int n_steps = 1;
-  while (n_steps < depth && steps[n_steps].done) n_steps++;
+  const int n_steps = chain_steps_done(steps, depth);
   if (blockIdx.x == 0 && threadIdx.x == 0) pass->n_steps = n_steps;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   int nz = 0;
@@ -1417,8 +1426,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_export_lookahead(
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (!kRatio && i >= sh.lda) return;
   double v = 0.0;
-  int n = pending > 0 ? 1 : 0;
-  while (n > 0 && n < pending && steps[n].done) n++;
+  const int n = pending > 0 ? chain_steps_done(steps, pending) : 0;
   if (l >= 0 && i < sh.m) v = chain_apply(T.col(l)[i], n, colp + i, sh.lda, rowp + l, rstride);   // the update leaves columns with row' == 0 alone
   if (i < sh.lda) xlocal[i] = v;
   if (kRatio) {
