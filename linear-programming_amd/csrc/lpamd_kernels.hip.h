@@ -820,48 +820,56 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   __shared__ int s_w;
-  if (st->status != ST_RUNNING) return;
+  __shared__ int64_t s_e2;
+  __shared__ double s_ce2;
+  // What decides whether the step exists is requested together, the exchange records (one per lane of the first
+  // wavefront) included: one round trip to data the launches before have just written instead of three.
+  const int32_t status = st->status;
+  const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
+  Candidate rec;
+  rec.key = -DBL_MAX; rec.gcol = -1; rec.row = -1; rec.ce = 0.0;
+  if (kSlots && slot_world <= kWave && (int)threadIdx.x < slot_world)
+    rec = *reinterpret_cast<const Candidate*>(slots + (size_t)threadIdx.x * slot_words);
+  if (status != ST_RUNNING) return;
   const bool keeper = (int)blockIdx.x == n_row_blocks && threadIdx.x == 0;   // the thread that records the step
   if (kSlots && j == 1 && keeper)   // the step records of the pass before (k_chain_ratio does this in the other loops)
     for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
-  if (j > 1 && !steps[j - 1].done) return;
+  if (!prev_done) return;
   int64_t e2;
   double ce2;
   if (kSlots) {
-    if (slot_world <= kWave) {          // one record per lane of the first wavefront: all loads at once
+    if (slot_world <= kWave) {
       if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
-        double key = -DBL_MAX;
-        int64_t gc = -1;
-        if (lane < slot_world) {
-          const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)lane * slot_words);
-          if (c.gcol >= 0) { key = c.key; gc = c.gcol; }
-        }
+        const double key = rec.gcol >= 0 ? rec.key : -DBL_MAX;
+        const int64_t gc = rec.gcol >= 0 ? rec.gcol : -1;
         double bk = key;
         int64_t bg = gc;
         wave_arg<true>(bk, bg);           // larger key, lower global column on ties
         bg = __shfl(bg, 0, kWave);
         const unsigned long long owner = __ballot(gc >= 0 && gc == bg);
-        if (lane == 0) s_w = bg < 0 ? -1 : __ffsll((long long)owner) - 1;
+        const int w = bg < 0 ? -1 : __ffsll((long long)owner) - 1;
+        if (lane == 0) s_w = w;
+        if (lane == w) { s_e2 = rec.gcol; s_ce2 = rec.ce; }
       }
     } else if (threadIdx.x == 0) {
       int w = -1;
-      double bk = 0.0;
-      int64_t bg = -1;
+      Candidate best = rec;
       for (int k = 0; k < slot_world; k++) {
         const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)k * slot_words);
         if (c.gcol < 0) continue;
-        if (w < 0 || c.key > bk || (c.key == bk && c.gcol < bg)) { w = k; bk = c.key; bg = c.gcol; }
+        if (w < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) { w = k; best = c; }
       }
       s_w = w;
+      s_e2 = best.gcol;
+      s_ce2 = best.ce;
     }
     __syncthreads();
     const int w = s_w;
     if (w < 0) return;                    // optimal after step j-1, or the budget ends with it
     const uint64_t* __restrict__ mine = slots + (size_t)w * slot_words;
-    const Candidate c = *reinterpret_cast<const Candidate*>(mine);
-    e2 = c.gcol;
-    ce2 = c.ce;
+    e2 = s_e2;
+    ce2 = s_ce2;
     colv = reinterpret_cast<const double*>(mine + slot_header);
     rv = colv + sh.lda;                   // the owner's ratio-test partials: values, then rows
     ri = reinterpret_cast<const int64_t*>(rv + n_ratio_part);
