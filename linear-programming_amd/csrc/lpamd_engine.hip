@@ -533,11 +533,6 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_ste
                        e->colp, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
   LP_TRY(check_launch("k_prb_rows"));
   const bool cached = e->prb_use_cache;
-  if (cached) {
-    hipLaunchKernelGGL(k_prb_fill, dim3((unsigned)((e->sh.nloc + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0, e->stream, e->T,
-                       e->sh, e->st, e->steps, j, e->colp, e->rowp, e->rstride, e->prb_info, e->prb_cache);
-    LP_TRY(check_launch("k_prb_fill"));
-  }
   const int n_bound_blocks = (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (e->sh.nloc + kWave - 1) / kWave));   // tiles of 64 columns
   hipLaunchKernelGGL(k_prb_bounds, dim3(n_bound_blocks), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
                      e->rowp, e->rstride, e->prb_info, e->prb_c, cached ? e->prb_cache : nullptr, e->prb_ub, e->prb_ucand, pv, pi, pf);

@@ -41,8 +41,6 @@ struct PrbInfo {
   int32_t jf[kPrbRows];        // steps its slot already holds
   int32_t slot_row[kPrbRows];  // row a slot holds (-1: none)
   int32_t slot_jf[kPrbRows];
-  int32_t n_fill, pad;         // rows of R to gather in this pricing
-  int32_t fill_row[kPrbRows], fill_slot[kPrbRows];
 };
 
 // true while step j of the pass may still be set up (the same tests k_chain_ratio makes)
@@ -250,13 +248,10 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     my_slot = __ffs(free_slots) - 1;       // n_rows <= kPrbRows slots: there is one
     info->slot_row[my_slot] = (int32_t)mine;
     info->slot_jf[my_slot] = j;
-    info->fill_row[nth] = (int32_t)mine;
-    info->fill_slot[nth] = my_slot;
   }
   if (lane < n_rows) { info->slot[lane] = my_slot; info->jf[lane] = hit ? s_slot_jf[my_slot] : j; }
   if (j == 0 && lane < kPrbRows && lane >= n_rows) info->slot_row[lane] = -1;   // step 0 fills slots 0..n_rows-1
   if (lane == 0) {
-    info->n_fill = __popcll(missing);
     info->n_rows = n_rows; info->n_list = 0; info->l1 = -1; info->first = -1; info->s1 = -DBL_MAX;
   }
 }
@@ -273,32 +268,9 @@ __device__ __forceinline__ bool prb_basic(int l, int j, const uint8_t* is_basic,
   return basic;
 }
 
-// 1d. the rows new to R, gathered into their cache slots for every local column as steps 0..j-1 leave them
-__global__ __launch_bounds__(kPartialThreads) void k_prb_fill(
-    Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
-    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info,
-    double* __restrict__ cache) {
-  if (!prb_step_alive(st, steps, j)) return;
-  const int n_fill = info->n_fill;
-  const int l = blockIdx.x * kPartialThreads + threadIdx.x;
-  if (n_fill <= 0 || l >= sh.nloc) return;
-  const double* __restrict__ col = T.col(l);
-  constexpr int kBatch = 8;
-  for (int q0 = 0; q0 < n_fill; q0 += kBatch) {
-    double v[kBatch];
-#pragma unroll
-    for (int q = 0; q < kBatch; q++) v[q] = q0 + q < n_fill ? col[info->fill_row[q0 + q]] : 0.0;   // independent sector loads
-#pragma unroll
-    for (int q = 0; q < kBatch; q++) {
-      if (q0 + q >= n_fill) break;
-      const int row = info->fill_row[q0 + q];
-      cache[(int64_t)info->fill_slot[q0 + q] * sh.nloc + l] = chain_apply(v[q], j, colp + row, sh.lda, rowp + l, rstride);
-    }
-  }
-}
-
 // 2. bound u_l per candidate column from the rows of R; per-workgroup arg-max (lowest column on ties)
-// and lowest candidate column.  A workgroup takes tiles of 64 columns; its four wavefronts share the rows of R
+// and lowest candidate column.  The rows new to R in this pricing are gathered from the tableau here, for every
+// local column (a 64-byte sector per column and row), brought through steps 0..j-1 and left in their cache slots.  A workgroup takes tiles of 64 columns; its four wavefronts share the rows of R
 // (a quarter each, combined through LDS): one thread per column and all rows is a chain of a few thousand dependent
 // instructions on a chip that this kernel fills with one wavefront per SIMD.
 constexpr int kPrbGroups = kPartialThreads / kWave;
@@ -307,7 +279,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
     Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
     const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
     const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info, const double* __restrict__ prb_c,
-    const double* __restrict__ cache,   // nullptr: the rows are gathered from the tableau itself
+    double* __restrict__ cache,         // nullptr: the rows are gathered from the tableau itself
     double* __restrict__ ub, uint8_t* __restrict__ ucand,
     double* __restrict__ pv, int64_t* __restrict__ pi, int64_t* __restrict__ pfirst) {
   __shared__ double s_mn[kPrbGroups][kWave];
@@ -317,15 +289,21 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int k0 = grp * kPrbPerGroup;
   int jf_min = j;
-  int jfs[kPrbPerGroup], slots[kPrbPerGroup];
+  int jfs[kPrbPerGroup], slots[kPrbPerGroup], rows[kPrbPerGroup];
+  bool fresh[kPrbPerGroup];      // new to R in this pricing: gathered from the tableau here and left in its cache slot
+  bool any_fresh = false;
   double bs[kPrbPerGroup];
 #pragma unroll
   for (int k = 0; k < kPrbPerGroup; k++) {
     const bool live = k0 + k < n_rows;
-    jfs[k] = live ? (cache ? info->jf[k0 + k] : 0) : j;
-    slots[k] = live ? (cache ? info->slot[k0 + k] : info->rows[k0 + k]) : 0;   // slot of the cache, or the row itself
+    const int jf = live ? (cache ? info->jf[k0 + k] : 0) : j;
+    rows[k] = live ? info->rows[k0 + k] : 0;
+    fresh[k] = live && cache && jf == j;          // slots filled by earlier pricings of the pass hold fewer steps
+    jfs[k] = fresh[k] ? 0 : jf;                   // a fresh row starts from the stored entry and takes every step
+    slots[k] = live ? (cache ? info->slot[k0 + k] : rows[k]) : 0;   // slot of the cache, or the row itself
     bs[k] = live ? info->b[k0 + k] : 0.0;
     jf_min = min(jf_min, jfs[k]);
+    any_fresh = any_fresh || fresh[k];
   }
   double bv = -DBL_MAX;
   int64_t bi = -1, fi = -1;
@@ -335,11 +313,11 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
     const double c = l < sh.nloc ? obj[l] : 0.0;
     const bool cand = l < sh.nloc && !prb_basic(l, j, is_basic, st, steps) && is_pos(c);
     double mn = DBL_MAX;   // no eligible row among this wavefront's rows
-    if (cand) {
+    if (cand || (any_fresh && l < sh.nloc)) {      // a fresh row is cached for EVERY local column: any of them may price later
       double a[kPrbPerGroup];
 #pragma unroll
       for (int k = 0; k < kPrbPerGroup; k++)
-        a[k] = k0 + k >= n_rows ? 0.0 : (cache ? cache[(int64_t)slots[k] * sh.nloc + l] : T.col(l)[slots[k]]);
+        a[k] = k0 + k >= n_rows ? 0.0 : ((cache && !fresh[k]) ? cache[(int64_t)slots[k] * sh.nloc + l] : T.col(l)[rows[k]]);
       constexpr int kBatch = 8;   // row' values fetched together: the steps depend on each other, their loads do not
       for (int s0 = jf_min; s0 < j; s0 += kBatch) {
         double r[kBatch];
@@ -356,7 +334,8 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
       }
 #pragma unroll
       for (int k = 0; k < kPrbPerGroup; k++) {
-        if (k0 + k < n_rows && (float)a[k] <= -1e-6f) {
+        if (fresh[k]) cache[(int64_t)slots[k] * sh.nloc + l] = a[k];   // as steps 0..j-1 leave it (jf = j)
+        if (cand && k0 + k < n_rows && (float)a[k] <= -1e-6f) {
           const double ratio = bs[k] / (-a[k]);
           if (ratio < mn) mn = ratio;
         }
