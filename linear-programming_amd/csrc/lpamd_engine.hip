@@ -1623,15 +1623,22 @@ int export_lookahead_ratio(lpamd_engine* e, uint64_t* slot, int header_words) {
 }
 
 // ... and the set-up of that pivot on every rank straight from the gathered slots (no fold kernel, no ratio-test launch).
-int chain_step_from_slots(lpamd_engine* e, const uint64_t* slots, int world, int64_t slot_words, int header_words) {
+// rows_given: MAX_REDUCTION, the records carry the pivot rows and no ratio-test partials.
+int chain_step_from_slots(lpamd_engine* e, const uint64_t* slots, int world, int64_t slot_words, int header_words, bool rows_given = false) {
   if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain step: no pivot has been set up by lpamd_lookahead_setup");
   if (e->pending_steps >= e->chain_depth) return set_err(LPAMD_E_STATE, "chain step: the pass already holds %d pivots", e->pending_steps);
   e->apply_since_pull++;
   LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
-  hipLaunchKernelGGL((k_chain_finalize<true, false, true>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh,
-                     e->st, e->steps, e->pending_steps, nullptr, nullptr, (int)slot_ratio_parts(e), e->n_row_blocks, e->colp, e->rowp, e->rstride,
-                     e->rhs_next, nullptr, nullptr, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i, slots, world,
-                     slot_words, header_words, e->chain_depth);
+  if (rows_given)
+    hipLaunchKernelGGL((k_chain_finalize<false, false, true>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh,
+                       e->st, e->steps, e->pending_steps, nullptr, nullptr, 0, e->n_row_blocks, e->colp, e->rowp, e->rstride,
+                       e->rhs_next, nullptr, nullptr, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i, slots, world,
+                       slot_words, header_words, e->chain_depth);
+  else
+    hipLaunchKernelGGL((k_chain_finalize<true, false, true>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh,
+                       e->st, e->steps, e->pending_steps, nullptr, nullptr, (int)slot_ratio_parts(e), e->n_row_blocks, e->colp, e->rowp, e->rstride,
+                       e->rhs_next, nullptr, nullptr, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->part_v, e->part_i, slots, world,
+                       slot_words, header_words, e->chain_depth);
   LP_TRY(check_launch("k_chain_finalize"));
   e->price_partials_fresh = true;
   e->pending_steps++;

@@ -801,10 +801,11 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
 // kFindRow: the row comes from the ratio-test partials (MAX_COST); otherwise with the candidate
 // record `xcand` (MAX_REDUCTION prices column and row together).  kRebuild: the entering column is
 // a local column and is rebuilt here through the steps so far; otherwise it is given in `colv`.
-// kSlots (column shards, MAX_COST): the step is set up straight from the gathered exchange slots.  Every workgroup
+// kSlots (column shards): the step is set up straight from the gathered exchange slots.  Every workgroup
 // folds the ranks' candidate records itself (largest reduced cost, lowest global column on ties; reference
 // lp_simplex_tableau.cc:188-198), takes the winner's column from the winner's slot and folds the ratio-test partials
-// its owner left there (k_export_lookahead<true>), which replaces the fold kernel and k_chain_ratio of that step.
+// its owner left there (k_export_lookahead<true>), which replaces the fold kernel and k_chain_ratio of that step
+// (MAX_REDUCTION, kFindRow == false: the records bring their rows, and a record without a row does not compete).
 // The budget has been settled by the exporting kernel ("no candidate" once it is used up): this launch advances
 // the pivot count, so its workgroups cannot test it themselves.
 template <bool kFindRow, bool kRebuild, bool kSlots = false>
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   __shared__ int s_w;
-  __shared__ int64_t s_e2;
+  __shared__ int64_t s_e2, s_r2;
   __shared__ double s_ce2;
   // What decides whether the step exists is requested together, the exchange records (one per lane of the first
   // wavefront) included: one round trip to data the launches before have just written instead of three.
@@ -841,8 +842,9 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     if (slot_world <= kWave) {
       if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
-        const double key = rec.gcol >= 0 ? rec.key : -DBL_MAX;
-        const int64_t gc = rec.gcol >= 0 ? rec.gcol : -1;
+        const bool valid = rec.gcol >= 0 && (kFindRow || rec.row >= 0);   // a record that brings its row (MAX_REDUCTION) needs one
+        const double key = valid ? rec.key : -DBL_MAX;
+        const int64_t gc = valid ? rec.gcol : -1;
         double bk = key;
         int64_t bg = gc;
         wave_arg<true>(bk, bg);           // larger key, lower global column on ties
@@ -850,19 +852,20 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
         const unsigned long long owner = __ballot(gc >= 0 && gc == bg);
         const int w = bg < 0 ? -1 : __ffsll((long long)owner) - 1;
         if (lane == 0) s_w = w;
-        if (lane == w) { s_e2 = rec.gcol; s_ce2 = rec.ce; }
+        if (lane == w) { s_e2 = rec.gcol; s_ce2 = rec.ce; s_r2 = rec.row; }
       }
     } else if (threadIdx.x == 0) {
       int w = -1;
       Candidate best = rec;
       for (int k = 0; k < slot_world; k++) {
         const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)k * slot_words);
-        if (c.gcol < 0) continue;
+        if (c.gcol < 0 || (!kFindRow && c.row < 0)) continue;
         if (w < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) { w = k; best = c; }
       }
       s_w = w;
       s_e2 = best.gcol;
       s_ce2 = best.ce;
+      s_r2 = best.row;
     }
     __syncthreads();
     const int w = s_w;
@@ -882,6 +885,8 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   if (kFindRow) {
     double best;
     fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2, s_v, s_i);
+  } else if (kSlots) {
+    r2 = s_r2;
   } else {
     r2 = xcand->gcol == e2 ? xcand->row : -1;
   }

@@ -468,6 +468,8 @@ int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t*
                              e->cand, s.xbuf, nullptr, 0);
           LP_TRY(check_launch("k_pick_winner"));
           LP_TRY(prb_shard_setup(e, e->cand, s.xbuf));
+        } else if (g->fused_step) {   // every workgroup of the set-up folds the records itself and takes column and row from the winner's slot
+          LP_TRY(chain_step_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords, true));
         } else {
           hipLaunchKernelGGL(k_pick_winner<false>, dim3(pick_grid), dim3(256), 0, e->stream, s.slots, g->world, g->slot_words, e->sh, 1, e->st,
                              e->cand_la, s.xbuf, e->steps, j);
