@@ -74,7 +74,7 @@ struct lpamd_engine {
   int32_t slab_shape = 0;       // k_update_slab variant (0: k_update_chain)
   int32_t slab_grid = 4096;
   int32_t deep_batch = 0;       // > 0: k_update_deep with that many columns per batch (chains longer than 16)
-  int32_t deep_grid = 8192;
+  int32_t deep_grid = 0;        // workgroups of k_update_deep (0: sized from the shard, see launch_deep)
   int64_t rstride = 0;
   ChainStep* steps = nullptr;   // [kMaxChain]
   double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
@@ -466,7 +466,11 @@ bool launch_slab_shape(lpamd_engine* e) {
 template <int kC>
 void launch_deep(lpamd_engine* e) {
   const int n_slabs = (int)(e->sh.lda / (2 * kWave));
-  const int n_grp = std::max(1, e->deep_grid / n_slabs);
+  // Measured (full shard, 2-, 4- and 8-GPU shards of m=32768 n=65536): a wavefront should walk about 48 batches; fewer and
+  // the start of a stream (col' slices into LDS, a first batch nobody prefetched) shows, more and the chip drains unevenly.
+  constexpr int kWavesPerGroup = kDeepThreads / kWave, kBatchesPerWave = 48;
+  const int n_auto = std::max(1, (e->ncl / kC + kWavesPerGroup * kBatchesPerWave / 2) / (kWavesPerGroup * kBatchesPerWave));
+  const int n_grp = e->deep_grid > 0 ? std::max(1, e->deep_grid / n_slabs) : n_auto;
   const size_t lds = sizeof(double2) * kWave * (size_t)e->chain_depth;
   if (e->update_nt)
     hipLaunchKernelGGL((k_update_deep<kC, true>), dim3(n_slabs * n_grp), dim3(kDeepThreads), lds, e->stream, e->T, e->sh.lda, e->colp, e->pass,
@@ -848,7 +852,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->deep_batch = (e->chain_depth > 16 && e->sh.lda % (2 * kWave) == 0) ? 8 : 0;
   if (const char* env = getenv("LPAMD_DEEP")) e->deep_batch = (e->chain_depth > 1 && e->sh.lda % (2 * kWave) == 0) ? atoi(env) : 0;
   if (e->deep_batch != 4 && e->deep_batch != 8) e->deep_batch = 0;
-  if (const char* env = getenv("LPAMD_DEEP_GRID")) e->deep_grid = std::max(1, atoi(env));
+  if (const char* env = getenv("LPAMD_DEEP_GRID")) e->deep_grid = std::max(0, atoi(env));
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
   } else {
