@@ -832,14 +832,15 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_TWO_LAUNCH")) e->two_launch = world == 1 && atoi(env) != 0;
   // Longer columns: a pivot is bound by the HBM pass, so a chain of pivots shares one (see k_update_chain)
   // (column shards chain through lpamd_chain_step, the caller runs the exchange of every step)
-  // Depth: 16 steps still hide under the HBM time of the pass (k_update_slab, col' in registers).  Beyond about 20
-  // the fp64 vector rate (two instructions per entry and step plus the magnitude tracking) shows and the pass
-  // grows by 0.09 .. 0.18 ms per step at m=32768 n=65536 while a step's set-up costs 0.03 ms: 23 steps
-  // (k_update_deep, 5.97 ms per pass against 5.65, still 0.72 of the HBM peak) give 3450 pivots/s against 2600,
-  // 32 steps 3730 at 7.6 ms per pass (0.57 of the peak).  Shards that fit the Infinity Cache are bound by the
-  // set-up launches and stay at 16.
+  // Depth: 16 steps still hide under the HBM time of the pass (k_update_slab, col' in registers), and so do about 20
+  // with the col' slices in LDS (k_update_deep).  Beyond that the fp64 vector rate (two instructions per entry and
+  // step plus the magnitude tracking) shows and the pass grows by 0.1 .. 0.2 ms per step at m=32768 n=65536 while a
+  // step's set-up costs 0.03 ms: 22 steps cost 5.8 ms per pass against 5.65 (0.73 of the HBM peak, 3420 pivots/s
+  // against 2600 at 16), 23 steps 5.9 .. 6.1 ms (0.70 .. 0.73 from one machine to the next), 32 steps 7.5 ms (0.57 of
+  // the peak, 3800 pivots/s).  The default is the deepest chain that keeps the pass clear of 0.70 of the peak on
+  // every machine seen.  Shards that fit the Infinity Cache are bound by the set-up launches and stay at 16.
   const bool hbm_sized = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
-  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 23 : 16);
+  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 22 : 16);
   if (const char* env = getenv("LPAMD_CHAIN")) {
     e->chain_depth = std::max(1, std::min(kMaxChain, atoi(env)));
     if (e->chain_depth > 1) e->two_launch = false;

@@ -16,8 +16,8 @@ stats() {   # stats <name> <bench args...>: rocprofv3 kernel stats of one bench 
 pmc() {     # pmc <name> <bench args...>: the two PMC passes and their reduction
   local name=$1; shift
   echo "pmc $name"
-  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 46 --warmup 23 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
-  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 46 --warmup 23 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 44 --warmup 22 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 44 --warmup 22 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
   python3 scripts/pmc_traffic.py $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json > $o/pmc_hbm_traffic_$name.json
   rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json $o/pmc_write.json
 }
@@ -55,7 +55,7 @@ r=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('depth $d', r['value'], 'pivots/s', r['roofline']['avg_launch_ms'], 'ms/pass', r['roofline']['achieved'], 'GB/s', r['roofline']['kernel'])
 " >> $o/sweep_depth_m32768_n65536.txt
 done
-for d in 16 23 32; do
+for d in 16 22 32; do
   LPAMD_CHAIN=$d timeout -k 10 200 python3 -u bench.py --strategy max_reduction --steps $((d*4)) --warmup $d --no-cpu-baseline 2>> $o/err.log | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.read().strip().splitlines()[-1])

@@ -84,7 +84,7 @@ def _sample_columns(rng, n, N, trace, k):
 
 def test_m32768_n65536_two_chained_passes_bit_exact(lpamd, monkeypatch):
     """The configuration of the headline benchmark at its own size: two full passes of the default
-    chained loop (46 pivots at 23 per pass) against the oracle (reference lp_simplex_tableau.cc:10-52, 188-227), every
+    chained loop (44 pivots at 22 per pass) against the oracle (reference lp_simplex_tableau.cc:10-52, 188-227), every
     entry of the 25.8 GB tableau included; then the same pivots with one pass per pivot."""
     m, n, seed = 32768, 65536, 1
     N = n + m
