@@ -857,6 +857,15 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_DEEP_GRID")) e->deep_grid = std::max(0, atoi(env));
   if (hip_stream) {
     e->stream = (hipStream_t)hip_stream;
+  } else if (const char* env = getenv("LPAMD_STREAM_CU_RANGE")) {
+    // experiments only ("first:last"): the engine's own stream restricted to CUs first .. last-1 of the device
+    int first = 0, last = 0;
+    if (sscanf(env, "%d:%d", &first, &last) != 2 || first < 0 || last <= first || last > 1024)
+      return set_err(LPAMD_E_ARG, "LPAMD_STREAM_CU_RANGE wants first:last");
+    std::vector<uint32_t> mask((last + 31) / 32, 0u);
+    for (int c = first; c < last; c++) mask[c / 32] |= 1u << (c % 32);
+    HIP_TRY(hipExtStreamCreateWithCUMask(&e->stream, (uint32_t)mask.size(), mask.data()));
+    e->own_stream = true;
   } else {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     e->own_stream = true;
