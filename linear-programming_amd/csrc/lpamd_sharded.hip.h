@@ -15,8 +15,11 @@
 // key, lowest global column on ties) and reads the winner's column from the winner's slot.
 // Sending a column that may lose costs bandwidth (world * 8 * m bytes per pivot, 2 MiB at
 // m = 32768 over 8 ranks) and saves the second, dependent collective; both are latency-bound.
-// Everything else (ratio test on the RHS replica, row gather, rank-1 update) is rank-local
-// and bit-identical across ranks.
+// Everything else (row gather, rank-1 update) is rank-local and bit-identical across ranks.
+// Inside a chain of MAX_COST pivots the owner of a candidate also takes the ratio-test partials
+// on its column (the right-hand side is replicated) and sends them behind the column, and the
+// set-up kernel of every rank folds records and partials itself: two launches and the
+// collective per pivot (fused_step; MAX_REDUCTION records bring their rows instead).
 //
 // LPAMD_GROUP_LOCAL_EXCHANGE replaces RCCL by device copies between the shards of one process
 // (events + host barriers).  It exists so that several shards can share ONE GPU, which RCCL
@@ -363,8 +366,9 @@ int export_lookahead(Shard& s) {
 
 // MAX_COST: look-ahead exchange and chains of pivots per pass (see lpamd.h, lpamd_lookahead_* and
 // lpamd_chain_step).  Per pass: set-up of the first pivot on the column the previous exchange
-// delivered; chain - 1 times {export, exchange, lpamd_chain_step}; export + exchange of the next
-// pass's first pivot on the exchange stream while the pass streams the shard.
+// delivered; chain - 1 times {export with ratio-test partials, all-gather, set-up straight from the
+// slots} (or, without fused_step, {export, exchange + fold kernel, lpamd_chain_step}); export +
+// exchange of the next pass's first pivot on the exchange stream while the pass streams the shard.
 int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done) {
   lpamd_engine* e = s.eng;
   int64_t start = 0;
