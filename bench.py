@@ -197,7 +197,7 @@ def main():
         eng = group.engine(0)
         run = lambda k: group.run_pivots(strat, k)
         depth = group.chain()
-        exchange = "one RCCL all-gather per pivot (record + candidate column per rank), inside the library"
+        exchange = "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library"
 
     K, W = args.steps, args.warmup
     if not args.exact_steps:
