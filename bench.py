@@ -161,7 +161,9 @@ def main():
     # RCCL launches, no wire time; the pivots are not the LP's, the work per pivot is that rank's).
     shard_of = int(os.environ.get("LPAMD_BENCH_SHARD_OF", "0"))
     force_sharded = os.environ.get("LPAMD_BENCH_FORCE_SHARDED", "0") == "1" or shard_of > 1
-    use_dist = world > 1
+    # LPAMD_BENCH_FORCE_DIST=1 (under torch.distributed.run with one rank): the process-per-GPU path of N > 1 with a
+    # world of one: torch's process group, the communicator id broadcast, ShardGroup.join.
+    use_dist = world > 1 or (os.environ.get("LPAMD_BENCH_FORCE_DIST", "0") == "1" and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -178,7 +180,7 @@ def main():
             torch.cuda.synchronize()
 
     group = None
-    if world == 1 and not force_sharded:
+    if world == 1 and not force_sharded and not use_dist:
         eng = lp.TableauEngine(m, N)
         eng.fill_synthetic(n, args.seed)
         run = lambda k: eng.run_pivots(strat, k)
