@@ -37,7 +37,12 @@ $(BINDIR)/lp_host_selftest: $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h) $(LIBDIR)/
 oracle:
 	$(MAKE) -C oracle
 
+# experiments only: the engine with wall-clock checkpoints in the set-up kernels (scripts/setup_timeline.py)
+dbg-clock:
+	@mkdir -p bin_scratch
+	$(HIPCC) $(HIPFLAGS) -DLPAMD_DBG_CLOCK -shared -o bin_scratch/liblpamd_dbgclock.so $(CSRC)/lpamd_engine.hip
+
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) build
 	$(MAKE) -C oracle clean
-.PHONY: all engine host host-bins oracle clean
+.PHONY: all engine host host-bins oracle clean dbg-clock

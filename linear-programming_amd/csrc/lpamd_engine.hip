@@ -1689,3 +1689,12 @@ int lpamd_poll(lpamd_engine* e, int32_t* result) {
 #include "lpamd_revised.hip.h"
 #include "lpamd_noalloc.hip.h"
 #include "lpamd_sharded.hip.h"
+
+#ifdef LPAMD_DBG_CLOCK
+// experiments only: the checkpoint clocks of the last pass (kMaxChain x 4 x 8 values of the 100 MHz wall clock)
+extern "C" int lpamd_dbg_clock(unsigned long long* out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lpamd::g_dbg_clock), sizeof(unsigned long long) * lpamd::kMaxChain * 4 * 8));
+  return LPAMD_OK;
+}
+#endif

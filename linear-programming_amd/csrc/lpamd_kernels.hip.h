@@ -86,6 +86,24 @@ struct Shape {
   int32_t rank, world;
 };
 
+// Timeline of the set-up kernels of a chain (experiments only, -DLPAMD_DBG_CLOCK): the 100 MHz wall clock at
+// checkpoints of step j, kept per step for the last pass; who = 0 k_chain_ratio, 1 k_chain_finalize row block 0,
+// 2 k_chain_finalize column block 0, 3 the last workgroup of k_chain_finalize.  Read back with lpamd_dbg_clock.
+#ifdef LPAMD_DBG_CLOCK
+__device__ unsigned long long g_dbg_clock[kMaxChain][4][8];
+#define LPAMD_CLK(j, who, cp, cond) do { if ((cond) && threadIdx.x == 0) g_dbg_clock[j][who][cp] = wall_clock64(); } while (0)
+// the same with the clocks held in registers until the end of the kernel (a store between the loads of a kernel is
+// one more thing their waits wait for)
+#define LPAMD_CLKR_DECL unsigned long long clk_r[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define LPAMD_CLKR(cp, cond) do { if (cond) clk_r[cp] = wall_clock64(); } while (0)
+#define LPAMD_CLKR_FLUSH(j, who, cond) do { if ((cond) && threadIdx.x == 0) for (int q_ = 0; q_ < 8; q_++) g_dbg_clock[j][who][q_] = clk_r[q_]; } while (0)
+#else
+#define LPAMD_CLK(j, who, cp, cond) do { } while (0)
+#define LPAMD_CLKR_DECL do { } while (0)
+#define LPAMD_CLKR(cp, cond) do { } while (0)
+#define LPAMD_CLKR_FLUSH(j, who, cond) do { } while (0)
+#endif
+
 // reference base.h:61-66: the predicates take float, so the double is narrowed first.
 __device__ __forceinline__ bool is_pos(double x) { return (float)x >= 1e-6f; }
 __device__ __forceinline__ bool is_neg(double x) { return (float)x <= -1e-6f; }
@@ -105,18 +123,55 @@ __device__ __forceinline__ void take_min(double& bv, int64_t& bi, double v, int6
   if (i >= 0 && (bi < 0 || v < bv || (v == bv && i < bi))) { bv = v; bi = i; }
 }
 
-template <bool kMax>
-__device__ __forceinline__ void wave_arg(double& v, int64_t& i) {
-#pragma unroll
-  for (int off = kWave / 2; off > 0; off >>= 1) {
-    const double ov = __shfl_down(v, off, kWave);
-    const int64_t oi = __shfl_down(i, off, kWave);
-    if (kMax) take_max(v, i, ov, oi); else take_min(v, i, ov, oi);
-  }
+// Lane exchange inside a row of 16 lanes through the data-parallel-primitive path of the vector ALU (a few cycles;
+// a shuffle through the LDS crossbar costs a hundred and more, and the arg-reductions below sit on the critical
+// path of every short set-up kernel): quad_perm [1,0,3,2] and [2,3,0,1], row_half_mirror, row_mirror.
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+template <int kCtrl> __device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, kCtrl, 0xF, 0xF, false); }
+template <int kCtrl> __device__ __forceinline__ double dpp_f64(double x) {
+  return __hiloint2double(dpp_i32<kCtrl>(__double2hiint(x)), dpp_i32<kCtrl>(__double2loint(x)));
+}
+template <int kCtrl> __device__ __forceinline__ int64_t dpp_i64(int64_t x) {
+  const int lo = dpp_i32<kCtrl>((int)(uint32_t)x), hi = dpp_i32<kCtrl>((int)(x >> 32));
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ int64_t readlane_i64(int64_t x, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)x, lane), hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
+  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// Wavefront-level arg-reduce followed by an LDS stage across the block's waves.
-// Result valid in thread 0.
+// Arg-reduce over the 64 lanes of a wavefront; EVERY lane gets the winner.  All lanes must be active.  The order
+// "better key, lower index on ties" is total over the valid entries, so the butterfly inside the rows of 16 lanes and
+// the fold of the four rows give every lane the same pair.
+template <bool kMax, int kCtrl>
+__device__ __forceinline__ void wave_arg_step(double& v, int64_t& i) {
+  const double ov = dpp_f64<kCtrl>(v);
+  const int64_t oi = dpp_i64<kCtrl>(i);
+  if (kMax) take_max(v, i, ov, oi); else take_min(v, i, ov, oi);
+}
+template <bool kMax>
+__device__ __forceinline__ void wave_arg(double& v, int64_t& i) {
+  wave_arg_step<kMax, kDppXor1>(v, i);
+  wave_arg_step<kMax, kDppXor2>(v, i);
+  wave_arg_step<kMax, kDppHalfMirror>(v, i);
+  wave_arg_step<kMax, kDppMirror>(v, i);
+  double rv = readlane_f64(v, 0);
+  int64_t ri = readlane_i64(i, 0);
+#pragma unroll
+  for (int row = 1; row < kWave / 16; row++) {
+    const double ov = readlane_f64(v, 16 * row);
+    const int64_t oi = readlane_i64(i, 16 * row);
+    if (kMax) take_max(rv, ri, ov, oi); else take_min(rv, ri, ov, oi);
+  }
+  v = rv;
+  i = ri;
+}
+
+// Wavefront-level arg-reduce, then every thread folds the wavefronts' winners from LDS: every thread of the
+// workgroup gets the result.  s_v / s_i hold one entry per wavefront and may be reused after the call.
 template <bool kMax, int kThreads>
 __device__ __forceinline__ void block_arg(double& v, int64_t& i, double* s_v, int64_t* s_i) {
   constexpr int kWaves = kThreads / kWave;
@@ -124,10 +179,11 @@ __device__ __forceinline__ void block_arg(double& v, int64_t& i, double* s_v, in
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   if (lane == 0) { s_v[wave] = v; s_i[wave] = i; }
   __syncthreads();
-  if (wave == 0) {
-    v = lane < kWaves ? s_v[lane] : 0.0;
-    i = lane < kWaves ? s_i[lane] : -1;
-    wave_arg<kMax>(v, i);
+  v = s_v[0];
+  i = s_i[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; w++) {
+    if (kMax) take_max(v, i, s_v[w], s_i[w]); else take_min(v, i, s_v[w], s_i[w]);
   }
   __syncthreads();
 }
@@ -145,11 +201,6 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ pv, con
     if (kMax) take_max(v, i, pv[k], pi[k]); else take_min(v, i, pv[k], pi[k]);
   }
   block_arg<kMax, kThreads>(v, i, s_v, s_i);
-  if (threadIdx.x == 0) { s_v[0] = v; s_i[0] = i; }
-  __syncthreads();
-  v = s_v[0];
-  i = s_i[0];
-  __syncthreads();
 }
 
 // MAX_COST pricing (reference lp_simplex_tableau.cc:188-198): largest positive
@@ -747,6 +798,7 @@ __device__ __forceinline__ double chain_apply(double v, int j, const double* __r
 // reference lp_simplex_tableau.cc:207-227 on it and on the right-hand side after step j-1.
 // kExternal (column shards): the entering column has been chosen among all ranks and arrives,
 // already rebuilt by its owner, in `colv` together with the candidate record `xcand`.
+// What decides whether the step exists is requested together with the pricing partials, before the first wait.
 template <bool kExternal>
 __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
@@ -755,30 +807,53 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     double* __restrict__ colv, double* __restrict__ rv, int64_t* __restrict__ ri, const Candidate* __restrict__ xcand) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
-  if (st->status != ST_RUNNING) return;
+  LPAMD_CLKR_DECL;
+  LPAMD_CLKR(0, blockIdx.x == 0);
+  const int64_t stride = (int64_t)gridDim.x * kPartialThreads;
+  const int64_t i0 = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x;
+  const bool have0 = i0 < sh.m;
+  const double* __restrict__ rhs = rhsv + (int64_t)(j - 1) * sh.lda;
+  const int32_t status = st->status;
+  LPAMD_CLKR(7, blockIdx.x == 0 && status != 99);
+  const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
+  const int64_t iter = st->iter, max_iter = st->max_iter;
+  const double rhs0 = have0 ? rhs[i0] : 0.0;
+  double ce = -DBL_MAX;
+  int64_t l = -1;
+  int64_t xe = -1;
+  double xce = 0.0;
+  if (kExternal) {
+    xe = xcand->gcol;
+    xce = xcand->ce;
+  } else {
+    for (int k = threadIdx.x; k < n_price_part; k += kPartialThreads) take_max(ce, l, pv[k], pi[k]);
+  }
+  if (status != ST_RUNNING) return;
+  LPAMD_CLKR(4, blockIdx.x == 0);
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
   if (j == 1) {
     if (lead) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
-  } else if (!steps[j - 1].done) {
+  } else if (!prev_done) {
     return;                               // the chain ended before this step
   }
-  if (st->iter >= st->max_iter) return;   // the budget ends with step j-1
-  double ce;
-  int64_t l = 0;
+  if (iter >= max_iter) return;           // the budget ends with step j-1
+  LPAMD_CLKR(5, blockIdx.x == 0);
+  LPAMD_CLKR(6, blockIdx.x == 0 && l != -5 && rhs0 == rhs0);
   if (kExternal) {
-    const int64_t e = xcand->gcol;
-    if (e < 0) return;                    // optimal after step j-1
-    if (lead) { steps[j].e = e; steps[j].ce = xcand->ce; }
+    if (xe < 0) return;                   // optimal after step j-1
+    if (lead) { steps[j].e = xe; steps[j].ce = xce; }
+    l = 0;
   } else {
-    fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
+    block_arg<true, kPartialThreads>(ce, l, s_v, s_i);
     if (l < 0) return;                    // optimal after step j-1
+    l = __builtin_amdgcn_readfirstlane((int)l);   // the same in every lane: row' of this column comes through scalar loads
     if (lead) { steps[j].e = gcol_of(l * sh.world + sh.rank, sh.N); steps[j].ce = ce; }
   }
+  LPAMD_CLKR(1, blockIdx.x == 0);
   const double* __restrict__ col = T.col(l);
-  const double* __restrict__ rhs = rhsv + (int64_t)(j - 1) * sh.lda;
   double bv = DBL_MAX;
   int64_t bi = -1;
-  for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
+  for (int64_t i = i0; i < sh.m; i += stride) {
     double a;
     if (kExternal) {
       a = colv[i];
@@ -787,11 +862,14 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
       colv[i] = a;
     }
     if ((float)a > -1e-6f) continue;
-    const double ratio = rhs[i] / (-a);
+    const double ratio = (i == i0 ? rhs0 : rhs[i]) / (-a);
     if (bv > ratio) { bv = ratio; bi = i; }
   }
+  LPAMD_CLKR(2, blockIdx.x == 0);
   block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
   if (threadIdx.x == 0) { rv[blockIdx.x] = bv; ri[blockIdx.x] = bi; }
+  LPAMD_CLKR(3, blockIdx.x == 0);
+  LPAMD_CLKR_FLUSH(j, 0, blockIdx.x == 0);
 }
 
 // Set-up of step j (reference lp_simplex_tableau.cc:10-44 on the tableau after step j-1): row
@@ -823,32 +901,67 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   __shared__ int s_w;
   __shared__ int64_t s_e2, s_r2;
   __shared__ double s_ce2;
-  // What decides whether the step exists is requested together, the exchange records (one per lane of the first
-  // wavefront) included: one round trip to data the launches before have just written instead of three.
+  LPAMD_CLK(j, 1, 0, blockIdx.x == 0);
+  LPAMD_CLK(j, 2, 0, (int)blockIdx.x == n_row_blocks);
+  LPAMD_CLK(j, 3, 0, blockIdx.x == gridDim.x - 1);
+  // A lone wavefront issues an instruction every four to five cycles and waits 0.3 - 0.5 us for a round trip to data
+  // the launches before have just written, so this kernel is as long as its longest wavefront's instruction stream and
+  // chain of waits.  Requested before the first wait: what decides whether the step exists, the exchange records (one
+  // per lane of the first wavefront), the ratio-test partials, the entries of the row or column this thread owns, and
+  // the records of the steps so far, one per LANE of every wavefront (lane 0 stands for pivot 0, which lives in
+  // PivotState): "which step pivoted on this row last" is then one ballot, and the basis flags of a column after the
+  // steps so far take two lane reads per step instead of two scalar loads and a wait.
+  const int lane = threadIdx.x & (kWave - 1);
+  const bool row_block = (int)blockIdx.x < n_row_blocks;
+  const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
+  const int ncl = sh.nloc + 1;
+  const double* __restrict__ rhs_prev = rhsv + (int64_t)(j - 1) * sh.lda;
   const int32_t status = st->status;
   const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
   Candidate rec;
   rec.key = -DBL_MAX; rec.gcol = -1; rec.row = -1; rec.ce = 0.0;
   if (kSlots && slot_world <= kWave && (int)threadIdx.x < slot_world)
     rec = *reinterpret_cast<const Candidate*>(slots + (size_t)threadIdx.x * slot_words);
+  int32_t q_in = -1, q_out = -1;   // step `lane`: local columns that turn basic / non-basic, entering variable, pivot row
+  int64_t q_e = -1, q_r = -1;
+  if (lane == 0) { q_in = st->l_e; q_out = st->l_d; q_e = st->e; q_r = st->r; }
+  else if (lane < j) { q_in = steps[lane].l_in; q_out = steps[lane].l_out; q_e = steps[lane].e; q_r = steps[lane].r; }
+  int64_t e2 = kSlots ? -1 : steps[j].e;
+  double ce2 = kSlots ? 0.0 : steps[j].ce;
+  const int64_t x_gcol = (!kFindRow && !kSlots) ? xcand->gcol : -1, x_row = (!kFindRow && !kSlots) ? xcand->row : -1;
+  double best = DBL_MAX;
+  int64_t r2 = -1;
+  if (kFindRow && !kSlots)
+    for (int k = threadIdx.x; k < n_ratio_part; k += kPartialThreads) take_min(best, r2, rv[k], ri[k]);
+  // the row (row blocks) or column (column blocks) whose operands wait in registers
+  const int64_t i0 = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x;
+  const bool have_row = row_block && i0 < sh.m;
+  const int l0 = cb * kPartialThreads + (int)threadIdx.x;
+  const bool have_col = !row_block && l0 < ncl;
+  double rhs0 = 0.0, colv0 = 0.0, obj0 = 0.0;
+  uint8_t basic0 = 0;
+  if (have_row) {
+    rhs0 = rhs_prev[i0];
+    if (!kRebuild && !kSlots) colv0 = colv[i0];
+  }
+  if (have_col) {
+    obj0 = obj[l0];
+    if (l0 < sh.nloc) basic0 = is_basic[l0];
+  }
   if (status != ST_RUNNING) return;
   const bool keeper = (int)blockIdx.x == n_row_blocks && threadIdx.x == 0;   // the thread that records the step
   if (kSlots && j == 1 && keeper)   // the step records of the pass before (k_chain_ratio does this in the other loops)
     for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
   if (!prev_done) return;
-  int64_t e2;
-  double ce2;
   if (kSlots) {
     if (slot_world <= kWave) {
       if (threadIdx.x < kWave) {
-        const int lane = threadIdx.x;
         const bool valid = rec.gcol >= 0 && (kFindRow || rec.row >= 0);   // a record that brings its row (MAX_REDUCTION) needs one
         const double key = valid ? rec.key : -DBL_MAX;
         const int64_t gc = valid ? rec.gcol : -1;
         double bk = key;
         int64_t bg = gc;
         wave_arg<true>(bk, bg);           // larger key, lower global column on ties
-        bg = __shfl(bg, 0, kWave);
         const unsigned long long owner = __ballot(gc >= 0 && gc == bg);
         const int w = bg < 0 ? -1 : __ffsll((long long)owner) - 1;
         if (lane == 0) s_w = w;
@@ -856,16 +969,16 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
       }
     } else if (threadIdx.x == 0) {
       int w = -1;
-      Candidate best = rec;
+      Candidate bestc = rec;
       for (int k = 0; k < slot_world; k++) {
         const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)k * slot_words);
         if (c.gcol < 0 || (!kFindRow && c.row < 0)) continue;
-        if (w < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) { w = k; best = c; }
+        if (w < 0 || c.key > bestc.key || (c.key == bestc.key && c.gcol < bestc.gcol)) { w = k; bestc = c; }
       }
       s_w = w;
-      s_e2 = best.gcol;
-      s_ce2 = best.ce;
-      s_r2 = best.row;
+      s_e2 = bestc.gcol;
+      s_ce2 = bestc.ce;
+      s_r2 = bestc.row;
     }
     __syncthreads();
     const int w = s_w;
@@ -876,21 +989,23 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     colv = reinterpret_cast<const double*>(mine + slot_header);
     rv = colv + sh.lda;                   // the owner's ratio-test partials: values, then rows
     ri = reinterpret_cast<const int64_t*>(rv + n_ratio_part);
+    if (have_row) colv0 = colv[i0];
+    if (kFindRow) {
+      for (int k = threadIdx.x; k < n_ratio_part; k += kPartialThreads) take_min(best, r2, rv[k], ri[k]);
+    } else {
+      r2 = s_r2;
+    }
   } else {
-    e2 = steps[j].e;
     if (e2 < 0) return;
-    ce2 = steps[j].ce;
+    if (!kFindRow) r2 = x_gcol == e2 ? x_row : -1;
   }
-  int64_t r2;
-  if (kFindRow) {
-    double best;
-    fold_partials<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2, s_v, s_i);
-  } else if (kSlots) {
-    r2 = s_r2;
-  } else {
-    r2 = xcand->gcol == e2 ? xcand->row : -1;
-  }
+  if (kFindRow) block_arg<false, kPartialThreads>(best, r2, s_v, s_i);
   if (r2 < 0) return;   // unbounded after step j-1: found again, and reported, by the next iteration
+  // the same in every lane: what hangs on the pivot row alone (col'_s at that row) comes through scalar loads
+  r2 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r2 >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r2));
+  LPAMD_CLK(j, 1, 1, blockIdx.x == 0);
+  LPAMD_CLK(j, 2, 1, (int)blockIdx.x == n_row_blocks);
   auto local_id = [&](int64_t g) -> int {
     if (g < 0 || g == sh.N) return -1;
     const int64_t o = ordinal_of(g, sh.N);
@@ -899,55 +1014,74 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   const int l_e2 = local_id(e2);
   if (kRebuild && l_e2 < 0) return;   // not reachable: a rebuilt column is a local one
   const double* __restrict__ ecol = kRebuild ? T.col(l_e2) : colv;
+  // ---- second round of requests: everything that hangs on the pivot row
+  const double* __restrict__ c_r = colp + r2;       // col'_s[r2] at c_r[s * lda]
+  double tv0 = 0.0;
+  int64_t b_r2 = -1;
+  if (!row_block) {
+    if (have_col) tv0 = T.col(l0)[r2];
+    b_r2 = basis[r2];
+  }
+  const double rhs_r2 = row_block ? rhs_prev[r2] : 0.0;
   const double a2 = kRebuild ? chain_apply(ecol[r2], j, colp + r2, sh.lda, rowp + l_e2, rstride) : colv[r2];
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
-  if ((int)blockIdx.x < n_row_blocks) {
+  LPAMD_CLK(j, 1, 2, blockIdx.x == 0 && g2 == g2);
+  LPAMD_CLK(j, 2, 2, (int)blockIdx.x == n_row_blocks && g2 == g2);
+  if (row_block) {
     double* __restrict__ cj = colp + (int64_t)j * sh.lda;
-    const double* __restrict__ rhs_prev = rhsv + (int64_t)(j - 1) * sh.lda;
     double* __restrict__ rhs_now = rhsv + (int64_t)j * sh.lda;
-    const double rp_rhs = __dmul_rn(rhs_prev[r2], f2);   // row'_j of the right-hand-side column
-    for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
-      const double ci = kRebuild ? chain_apply(ecol[i], j, colp + i, sh.lda, rowp + l_e2, rstride) : colv[i];
+    const double rp_rhs = __dmul_rn(rhs_r2, f2);   // row'_j of the right-hand-side column
+    const int64_t stride = (int64_t)n_row_blocks * kPartialThreads;
+    for (int64_t i = i0; i < sh.m; i += stride) {
+      const bool first = i == i0;
+      const double ci = kRebuild ? chain_apply(ecol[i], j, colp + i, sh.lda, rowp + l_e2, rstride) : (first ? colv0 : colv[i]);
+      const double rhs_i = first ? rhs0 : rhs_prev[i];
       const double cpi = (i == r2) ? __dadd_rn(1.0, a2) : ci;
       cj[i] = cpi;
-      rhs_now[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs_prev[i], __dmul_rn(cpi, rp_rhs))) : rhs_prev[i];
+      rhs_now[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs_i, __dmul_rn(cpi, rp_rhs))) : rhs_i;
     }
+    LPAMD_CLK(j, 1, 3, blockIdx.x == 0);
     return;
   }
-  const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
-  const int ncl = sh.nloc + 1;
-  // the basic variable of row r2 after steps 0..j-1 (basis[] is flipped by the pass kernel)
-  int64_t d2 = basis[r2];
-  if (st->r == r2) d2 = st->e;
-  for (int s = 1; s < j; s++)
-    if (steps[s].r == r2) d2 = steps[s].e;
-  const int l_d2 = local_id(d2);
-  const double* __restrict__ c_r = colp + r2;       // col'_s[r2] at c_r[s * lda]
-  double nbv = -DBL_MAX;
-  int64_t nbi = -1;
-  for (int l0 = cb * kPartialThreads; l0 < ncl; l0 += n_cb * kPartialThreads) {
-    const int l = l0 + threadIdx.x;
-    if (l < ncl) {
-      const double t = chain_apply(T.col(l)[r2], j, c_r, sh.lda, rowp + l, rstride);
-      const double rp2 = __dmul_rn(t, f2);
-      double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g2)));
-      if (l == l_e2) o = 0.0;
-      obj[l] = o;
-      rowp[(int64_t)j * rstride + l] = rp2;
-      if (l < sh.nloc) {
-        bool basic = is_basic[l] != 0;               // flags as before the pass, then the steps set up so far
-        if (l == st->l_e) basic = true; else if (l == st->l_d) basic = false;
-        for (int s = 1; s < j; s++) {
-          if (l == steps[s].l_in) basic = true; else if (l == steps[s].l_out) basic = false;
-        }
-        if (l == l_e2) basic = true; else if (l == l_d2) basic = false;
-        if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
-      }
+  // the basic variable of row r2 after steps 0..j-1 (basis[] is flipped by the pass kernel): the last step so far
+  // that pivoted on this row, else what the pass before left
+  int64_t d2 = b_r2;
+  {
+    const unsigned long long hit = __ballot(lane < j && q_r == r2);
+    if (hit) {
+      const int last = 63 - __clzll((long long)hit);
+      d2 = readlane_i64(q_e, last);
     }
   }
+  const int l_d2 = local_id(d2);
+  LPAMD_CLK(j, 2, 3, cb == 0 && l_d2 != -7);
+  double nbv = -DBL_MAX;
+  int64_t nbi = -1;
+  for (int l = l0; l < ncl; l += n_cb * kPartialThreads) {
+    const bool first = l == l0;
+    const double t = chain_apply(first ? tv0 : T.col(l)[r2], j, c_r, sh.lda, rowp + l, rstride);
+    const double rp2 = __dmul_rn(t, f2);
+    double o = flushz(__dadd_rn(first ? obj0 : obj[l], __dmul_rn(t, g2)));
+    if (l == l_e2) o = 0.0;
+    obj[l] = o;
+    rowp[(int64_t)j * rstride + l] = rp2;
+    if (l < sh.nloc) {
+      bool basic = (first ? basic0 : is_basic[l]) != 0;   // flags as before the pass, then the steps set up so far
+#pragma unroll 1
+      for (int s = 0; s < j; s++) {
+        const int in_s = __builtin_amdgcn_readlane(q_in, s), out_s = __builtin_amdgcn_readlane(q_out, s);
+        if (l == in_s) basic = true; else if (l == out_s) basic = false;
+      }
+      if (l == l_e2) basic = true; else if (l == l_d2) basic = false;
+      if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
+    }
+  }
+  LPAMD_CLK(j, 2, 4, cb == 0);
+  LPAMD_CLK(j, 3, 1, blockIdx.x == gridDim.x - 1);
   block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
   if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
+  LPAMD_CLK(j, 2, 5, cb == 0);
   if (cb == 0 && threadIdx.x == 0) {
     if (kSlots) { steps[j].e = e2; steps[j].ce = ce2; }
     steps[j].r = r2; steps[j].d = d2; steps[j].a = a2; steps[j].f = f2; steps[j].g = g2;

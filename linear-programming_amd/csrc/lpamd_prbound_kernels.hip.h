@@ -45,9 +45,13 @@ struct PrbInfo {
 
 // true while step j of the pass may still be set up (the same tests k_chain_ratio makes)
 __device__ __forceinline__ bool prb_step_alive(const PivotState* st, const ChainStep* steps, int j) {
-  if (st->status != ST_RUNNING) return false;
-  if (j > 1 && !steps[j - 1].done) return false;   // the chain ended before this step
-  if (j >= 1 && st->iter >= st->max_iter) return false;   // the budget ends with step j-1 (step 0 reports LIMIT itself)
+  // requested together: one round trip instead of three
+  const int32_t status = st->status;
+  const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
+  const int64_t iter = st->iter, max_iter = st->max_iter;
+  if (status != ST_RUNNING) return false;
+  if (!prev_done) return false;                     // the chain ended before this step
+  if (j >= 1 && iter >= max_iter) return false;     // the budget ends with step j-1 (step 0 reports LIMIT itself)
   return true;
 }
 
@@ -256,14 +260,15 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
   }
 }
 
-// basis flag of local column l after the pivots set up so far (the pass kernel flips is_basic[] later)
-__device__ __forceinline__ bool prb_basic(int l, int j, const uint8_t* is_basic, const PivotState* st, const ChainStep* steps) {
+// basis flag of local column l after the pivots set up so far (the pass kernel flips is_basic[] later).  q_in / q_out:
+// lane s of the wavefront holds the local columns step s turned basic / non-basic (lane 0: pivot 0, from PivotState), so
+// a step costs two lane reads instead of two scalar loads and a wait.
+__device__ __forceinline__ bool prb_basic(int l, int j, const uint8_t* is_basic, int q_in, int q_out) {
   bool basic = is_basic[l] != 0;
-  if (j >= 1) {
-    if (l == st->l_e) basic = true; else if (l == st->l_d) basic = false;
-    for (int s = 1; s < j; s++) {
-      if (l == steps[s].l_in) basic = true; else if (l == steps[s].l_out) basic = false;
-    }
+#pragma unroll 1
+  for (int s = 0; s < j; s++) {
+    const int in_s = __builtin_amdgcn_readlane(q_in, s), out_s = __builtin_amdgcn_readlane(q_out, s);
+    if (l == in_s) basic = true; else if (l == out_s) basic = false;
   }
   return basic;
 }
@@ -283,9 +288,12 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
     double* __restrict__ ub, uint8_t* __restrict__ ucand,
     double* __restrict__ pv, int64_t* __restrict__ pi, int64_t* __restrict__ pfirst) {
   __shared__ double s_mn[kPrbGroups][kWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  int q_in = -1, q_out = -1;     // the records of the steps so far, one per lane
+  if (lane == 0) { q_in = st->l_e; q_out = st->l_d; }
+  else if (lane < j) { q_in = steps[lane].l_in; q_out = steps[lane].l_out; }
   if (!prb_step_alive(st, steps, j)) return;
   const int n_rows = info->n_rows;
-  const int lane = threadIdx.x & (kWave - 1);
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int k0 = grp * kPrbPerGroup;
   int jf_min = j;
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int l = tile * kWave + lane;
     const double c = l < sh.nloc ? obj[l] : 0.0;
-    const bool cand = l < sh.nloc && !prb_basic(l, j, is_basic, st, steps) && is_pos(c);
+    const bool cand = l < sh.nloc && !prb_basic(l, j, is_basic, q_in, q_out) && is_pos(c);
     double mn = DBL_MAX;   // no eligible row among this wavefront's rows
     if (cand || (any_fresh && l < sh.nloc)) {      // a fresh row is cached for EVERY local column: any of them may price later
       double a[kPrbPerGroup];

@@ -27,7 +27,8 @@ class LpamdError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "lib", "liblpamd.so")
+    # LPAMD_LIBRARY: another build of the same library (experiments: instrumented kernels)
+    return os.environ.get("LPAMD_LIBRARY") or os.path.join(_HERE, "lib", "liblpamd.so")
 
 
 def library():
