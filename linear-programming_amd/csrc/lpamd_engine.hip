@@ -785,6 +785,9 @@ int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t
   const int64_t nloc = (n_ord - rank + world - 1) / world;
   if (nloc <= 0) return set_err(LPAMD_E_ARG, "more ranks than columns");
   if (nloc + 1 > (int64_t)std::numeric_limits<int32_t>::max() / 2) return set_err(LPAMD_E_ARG, "too many columns per rank");
+  // the kernels keep column ids and rows in 32 bits where that saves instructions (reductions, owner and local column of an id)
+  if (N + 2 > (int64_t)std::numeric_limits<int32_t>::max() || m > (int64_t)std::numeric_limits<int32_t>::max())
+    return set_err(LPAMD_E_ARG, "m and N must fit 31 bits");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
   lpamd_engine* e = new lpamd_engine();

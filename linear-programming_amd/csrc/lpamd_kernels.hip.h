@@ -113,6 +113,10 @@ __device__ __forceinline__ double flushz(double v) { return fabs(v) < (double)1e
 
 __host__ __device__ __forceinline__ int64_t ordinal_of(int64_t gcol, int64_t N) { return gcol < N ? gcol : N; }
 __host__ __device__ __forceinline__ int64_t gcol_of(int64_t ord, int64_t N) { return ord < N ? ord : N + 1; }
+// Owner rank and local column of ordinal o under the round-robin deal.  Ordinals fit 31 bits (checked at create), so
+// the division is a 32-bit one (a 64-bit division is some 150 instructions on this machine), and none on one GPU.
+__device__ __forceinline__ int ord_rank(int64_t o, int world) { return world == 1 ? 0 : (int)((uint32_t)o % (uint32_t)world); }
+__device__ __forceinline__ int ord_local(int64_t o, int world) { return world == 1 ? (int)o : (int)((uint32_t)o / (uint32_t)world); }
 
 // ---------------------------------------------------------------- reductions
 // "larger key wins, lower index breaks ties"; index -1 = empty.
@@ -128,67 +132,125 @@ __device__ __forceinline__ void take_min(double& bv, int64_t& bi, double v, int6
 // path of every short set-up kernel): quad_perm [1,0,3,2] and [2,3,0,1], row_half_mirror, row_mirror.
 constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
 template <int kCtrl> __device__ __forceinline__ int dpp_i32(int x) { return __builtin_amdgcn_update_dpp(x, x, kCtrl, 0xF, 0xF, false); }
-template <int kCtrl> __device__ __forceinline__ double dpp_f64(double x) {
-  return __hiloint2double(dpp_i32<kCtrl>(__double2hiint(x)), dpp_i32<kCtrl>(__double2loint(x)));
-}
-template <int kCtrl> __device__ __forceinline__ int64_t dpp_i64(int64_t x) {
-  const int lo = dpp_i32<kCtrl>((int)(uint32_t)x), hi = dpp_i32<kCtrl>((int)(x >> 32));
-  return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
-}
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
-}
 __device__ __forceinline__ int64_t readlane_i64(int64_t x, int lane) {
   const int lo = __builtin_amdgcn_readlane((int)(uint32_t)x, lane), hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
   return (int64_t)(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// Arg-reduce over the 64 lanes of a wavefront; EVERY lane gets the winner.  All lanes must be active.  The order
-// "better key, lower index on ties" is total over the valid entries, so the butterfly inside the rows of 16 lanes and
-// the fold of the four rows give every lane the same pair.
-template <bool kMax, int kCtrl>
-__device__ __forceinline__ void wave_arg_step(double& v, int64_t& i) {
-  const double ov = dpp_f64<kCtrl>(v);
-  const int64_t oi = dpp_i64<kCtrl>(i);
-  if (kMax) take_max(v, i, ov, oi); else take_min(v, i, ov, oi);
+// The arg-reductions run on an integer image of the pair: a 64-bit key that grows with "better" (the bits of the
+// double made order-preserving, complemented for a minimum; both zeros share a key; 0 = no entry, which no number
+// maps to) and the index as 32 bits (rows, local and global columns all fit; ~0 = none).  "Better key, lower index on
+// ties" is then a 64-bit maximum followed by a 32-bit minimum among the lanes that hold that maximum: straight-line
+// integer code, where the same rule written on (double, int64) compiles to a ladder of branches several times as long,
+// and these reductions sit on the critical path of every short set-up kernel (a lone wavefront issues an instruction
+// every four to five cycles).
+constexpr uint64_t kSignBit = 0x8000000000000000ull;
+constexpr uint32_t kNoIndex = 0xFFFFFFFFu;
+template <bool kMax>
+__device__ __forceinline__ uint64_t arg_key(double v, int64_t i) {
+  uint64_t b = (uint64_t)__double_as_longlong(v);
+  if ((b << 1) == 0) b = 0;                                   // -0.0 ranks with +0.0
+  uint64_t key = (b & kSignBit) ? ~b : (b | kSignBit);         // ascending with v
+  if (!kMax) key = ~key;
+  return i >= 0 ? key : 0;
 }
 template <bool kMax>
+__device__ __forceinline__ double arg_value(uint64_t key) {    // the number behind a key (+0.0 for either zero)
+  if (!kMax) key = ~key;
+  const uint64_t b = (key & kSignBit) ? (key & ~kSignBit) : ~key;
+  return __longlong_as_double((long long)b);
+}
+template <int kCtrl> __device__ __forceinline__ uint64_t dpp_u64(uint64_t x) {
+  const int lo = dpp_i32<kCtrl>((int)(uint32_t)x), hi = dpp_i32<kCtrl>((int)(x >> 32));
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t x, int lane) {
+  const int lo = __builtin_amdgcn_readlane((int)(uint32_t)x, lane), hi = __builtin_amdgcn_readlane((int)(x >> 32), lane);
+  return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t max_u64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+// Best (key, index) over the 64 lanes of a wavefront; EVERY lane gets it.  All lanes must be active.  Butterfly
+// inside the rows of 16 lanes, then the four rows through lane reads.
+__device__ __forceinline__ void wave_best(uint64_t& key, uint32_t& idx) {
+  uint64_t k = key;
+  k = max_u64(k, dpp_u64<kDppXor1>(k));
+  k = max_u64(k, dpp_u64<kDppXor2>(k));
+  k = max_u64(k, dpp_u64<kDppHalfMirror>(k));
+  k = max_u64(k, dpp_u64<kDppMirror>(k));
+  k = max_u64(max_u64(readlane_u64(k, 0), readlane_u64(k, 16)), max_u64(readlane_u64(k, 32), readlane_u64(k, 48)));
+  uint32_t c = key == k ? idx : kNoIndex;
+  c = min_u32(c, (uint32_t)dpp_i32<kDppXor1>((int)c));
+  c = min_u32(c, (uint32_t)dpp_i32<kDppXor2>((int)c));
+  c = min_u32(c, (uint32_t)dpp_i32<kDppHalfMirror>((int)c));
+  c = min_u32(c, (uint32_t)dpp_i32<kDppMirror>((int)c));
+  c = min_u32(min_u32((uint32_t)__builtin_amdgcn_readlane((int)c, 0), (uint32_t)__builtin_amdgcn_readlane((int)c, 16)),
+              min_u32((uint32_t)__builtin_amdgcn_readlane((int)c, 32), (uint32_t)__builtin_amdgcn_readlane((int)c, 48)));
+  key = k;
+  idx = c;
+}
+
+// Arg-reduce over the 64 lanes of a wavefront ("better value, lower index on ties", index < 0 = no entry); EVERY lane
+// gets the winner (index -1 when no lane had an entry).  All lanes must be active.
+template <bool kMax>
 __device__ __forceinline__ void wave_arg(double& v, int64_t& i) {
-  wave_arg_step<kMax, kDppXor1>(v, i);
-  wave_arg_step<kMax, kDppXor2>(v, i);
-  wave_arg_step<kMax, kDppHalfMirror>(v, i);
-  wave_arg_step<kMax, kDppMirror>(v, i);
-  double rv = readlane_f64(v, 0);
-  int64_t ri = readlane_i64(i, 0);
-#pragma unroll
-  for (int row = 1; row < kWave / 16; row++) {
-    const double ov = readlane_f64(v, 16 * row);
-    const int64_t oi = readlane_i64(i, 16 * row);
-    if (kMax) take_max(rv, ri, ov, oi); else take_min(rv, ri, ov, oi);
-  }
-  v = rv;
-  i = ri;
+  uint64_t key = arg_key<kMax>(v, i);
+  uint32_t idx = i >= 0 ? (uint32_t)i : kNoIndex;
+  wave_best(key, idx);
+  v = key ? arg_value<kMax>(key) : (kMax ? -DBL_MAX : DBL_MAX);
+  i = key ? (int64_t)idx : -1;
 }
 
 // Wavefront-level arg-reduce, then every thread folds the wavefronts' winners from LDS: every thread of the
-// workgroup gets the result.  s_v / s_i hold one entry per wavefront and may be reused after the call.
+// workgroup gets the result.  s_v / s_i hold one entry per wavefront (key bits and index) and may be reused after
+// the call.
 template <bool kMax, int kThreads>
 __device__ __forceinline__ void block_arg(double& v, int64_t& i, double* s_v, int64_t* s_i) {
   constexpr int kWaves = kThreads / kWave;
-  wave_arg<kMax>(v, i);
+  uint64_t key = arg_key<kMax>(v, i);
+  uint32_t idx = i >= 0 ? (uint32_t)i : kNoIndex;
+  wave_best(key, idx);
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  if (lane == 0) { s_v[wave] = v; s_i[wave] = i; }
+  if (lane == 0) { s_v[wave] = __longlong_as_double((long long)key); s_i[wave] = (int64_t)idx; }
   __syncthreads();
-  v = s_v[0];
-  i = s_i[0];
+  uint64_t ks[kWaves];
+  uint32_t cs[kWaves];
 #pragma unroll
-  for (int w = 1; w < kWaves; w++) {
-    if (kMax) take_max(v, i, s_v[w], s_i[w]); else take_min(v, i, s_v[w], s_i[w]);
-  }
+  for (int w = 0; w < kWaves; w++) { ks[w] = (uint64_t)__double_as_longlong(s_v[w]); cs[w] = (uint32_t)s_i[w]; }
+  uint64_t k = ks[0];
+#pragma unroll
+  for (int w = 1; w < kWaves; w++) k = max_u64(k, ks[w]);
+  uint32_t c = kNoIndex;
+#pragma unroll
+  for (int w = 0; w < kWaves; w++) c = min_u32(c, ks[w] == k ? cs[w] : kNoIndex);
   __syncthreads();
+  v = k ? arg_value<kMax>(k) : (kMax ? -DBL_MAX : DBL_MAX);
+  i = k ? (int64_t)c : -1;
 }
 
 // ------------------------------------------------------------------ pricing
+// This thread's share of up to kMaxPartials (value, index) partial results, folded into (v, i).  The loads of four
+// rounds are issued before the first compare: a round trip to data the launch before has just written costs half a
+// microsecond and more, and 256 < n <= 1024 is the usual case on HBM-sized shards.
+template <bool kMax, int kThreads>
+__device__ __forceinline__ void fold_share(const double* __restrict__ pv, const int64_t* __restrict__ pi, int n, double& v, int64_t& i) {
+  for (int k0 = threadIdx.x; k0 < n; k0 += 4 * kThreads) {
+    double vv[4];
+    int64_t ii[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + q * kThreads;
+      vv[q] = k < n ? pv[k] : 0.0;
+      ii[q] = k < n ? pi[k] : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (kMax) take_max(v, i, vv[q], ii[q]); else take_min(v, i, vv[q], ii[q]);
+    }
+  }
+}
+
 // Folds up to kMaxPartials (value, index) partial results; every thread of the
 // workgroup gets the winner.  Used redundantly by all workgroups of the kernel
 // that consumes the partials, which avoids an extra launch or a grid barrier.
@@ -197,9 +259,7 @@ __device__ __forceinline__ void fold_partials(const double* __restrict__ pv, con
                                               double& v, int64_t& i, double* s_v, int64_t* s_i) {
   v = kMax ? -DBL_MAX : DBL_MAX;
   i = -1;
-  for (int k = threadIdx.x; k < n; k += kThreads) {
-    if (kMax) take_max(v, i, pv[k], pi[k]); else take_min(v, i, pv[k], pi[k]);
-  }
+  fold_share<kMax, kThreads>(pv, pi, n, v, i);
   block_arg<kMax, kThreads>(v, i, s_v, s_i);
 }
 
@@ -409,7 +469,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
     e = cand->gcol;
     if (e < 0) { if (lead) st->status = ST_SOLVED; return; }
   }
-  const double* __restrict__ col = xcol ? xcol : T.col(ordinal_of(e, sh.N) / sh.world);
+  const double* __restrict__ col = xcol ? xcol : T.col(ord_local(ordinal_of(e, sh.N), sh.world));
   const double* __restrict__ rhs = T.col(sh.nloc);
   double bv = DBL_MAX;
   int64_t bi = -1;
@@ -449,7 +509,7 @@ __device__ __forceinline__ void pivot_setup_body(
     int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
     double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, PassInfo* __restrict__ pass, double* s_v, int64_t* s_i) {
   const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
-  const double* __restrict__ col = xcol ? xcol : T.col(eo / sh.world);
+  const double* __restrict__ col = xcol ? xcol : T.col(ord_local(eo, sh.world));
   const double a = col[r];
   const double f = -1.0 / a;                         // lp_simplex_tableau.cc:40
   const double g = __dmul_rn(c.ce, f);               // lp_simplex_tableau.cc:34-35
@@ -470,8 +530,8 @@ __device__ __forceinline__ void pivot_setup_body(
   const int ncl = sh.nloc + 1;
   const int64_t d_now = d_override >= 0 ? d_override : basis[r];   // read before the bookkeeping thread overwrites basis[r]
   const int64_t dord = (d_now >= 0 && d_now != sh.N) ? ordinal_of(d_now, sh.N) : -1;
-  const int l_e = (eo % sh.world == sh.rank) ? (int)(eo / sh.world) : -1;
-  const int l_d = (dord >= 0 && dord % sh.world == sh.rank) ? (int)(dord / sh.world) : -1;
+  const int l_e = (ord_rank(eo, sh.world) == sh.rank) ? ord_local(eo, sh.world) : -1;
+  const int l_d = (dord >= 0 && ord_rank(dord, sh.world) == sh.rank) ? ord_local(dord, sh.world) : -1;
   double nbv = -DBL_MAX;   // pricing partial of the NEXT iteration, on the updated objective row
   int64_t nbi = -1;
   for (int l0 = cb * kPartialThreads; l0 < ncl; l0 += n_cb * kPartialThreads) {
@@ -675,10 +735,10 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
     }
     // bookkeeping of reference lp_simplex_tableau.cc:16-28 for the pivot set up by k_pivot_finalize
     const int64_t e = st->e, d = st->d, eo = ordinal_of(e, sh.N);
-    if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+    if (ord_rank(eo, sh.world) == sh.rank) is_basic[ord_local(eo, sh.world)] = 1;
     if (d >= 0 && d != sh.N) {
       const int64_t dord = ordinal_of(d, sh.N);
-      if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+      if (ord_rank(dord, sh.world) == sh.rank) is_basic[ord_local(dord, sh.world)] = 0;
     }
     basis[st->r] = e;
   }
@@ -826,7 +886,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     xe = xcand->gcol;
     xce = xcand->ce;
   } else {
-    for (int k = threadIdx.x; k < n_price_part; k += kPartialThreads) take_max(ce, l, pv[k], pi[k]);
+    fold_share<true, kPartialThreads>(pv, pi, n_price_part, ce, l);
   }
   if (status != ST_RUNNING) return;
   LPAMD_CLKR(4, blockIdx.x == 0);
@@ -837,8 +897,6 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     return;                               // the chain ended before this step
   }
   if (iter >= max_iter) return;           // the budget ends with step j-1
-  LPAMD_CLKR(5, blockIdx.x == 0);
-  LPAMD_CLKR(6, blockIdx.x == 0 && l != -5 && rhs0 == rhs0);
   if (kExternal) {
     if (xe < 0) return;                   // optimal after step j-1
     if (lead) { steps[j].e = xe; steps[j].ce = xce; }
@@ -931,8 +989,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   const int64_t x_gcol = (!kFindRow && !kSlots) ? xcand->gcol : -1, x_row = (!kFindRow && !kSlots) ? xcand->row : -1;
   double best = DBL_MAX;
   int64_t r2 = -1;
-  if (kFindRow && !kSlots)
-    for (int k = threadIdx.x; k < n_ratio_part; k += kPartialThreads) take_min(best, r2, rv[k], ri[k]);
+  if (kFindRow && !kSlots) fold_share<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2);
   // the row (row blocks) or column (column blocks) whose operands wait in registers
   const int64_t i0 = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x;
   const bool have_row = row_block && i0 < sh.m;
@@ -991,7 +1048,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     ri = reinterpret_cast<const int64_t*>(rv + n_ratio_part);
     if (have_row) colv0 = colv[i0];
     if (kFindRow) {
-      for (int k = threadIdx.x; k < n_ratio_part; k += kPartialThreads) take_min(best, r2, rv[k], ri[k]);
+      fold_share<false, kPartialThreads>(rv, ri, n_ratio_part, best, r2);
     } else {
       r2 = s_r2;
     }
@@ -1009,7 +1066,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   auto local_id = [&](int64_t g) -> int {
     if (g < 0 || g == sh.N) return -1;
     const int64_t o = ordinal_of(g, sh.N);
-    return (o % sh.world == sh.rank) ? (int)(o / sh.world) : -1;
+    return (ord_rank(o, sh.world) == sh.rank) ? ord_local(o, sh.world) : -1;
   };
   const int l_e2 = local_id(e2);
   if (kRebuild && l_e2 < 0) return;   // not reachable: a rebuilt column is a local one
@@ -1160,10 +1217,10 @@ __device__ __forceinline__ void chain_bookkeeping(PivotState* st, ChainStep* ste
                                                   uint8_t* is_basic, int64_t* basis) {
   auto flip = [&](int64_t e, int64_t d, int64_t r) {
     const int64_t eo = ordinal_of(e, sh.N);
-    if (eo % sh.world == sh.rank) is_basic[eo / sh.world] = 1;
+    if (ord_rank(eo, sh.world) == sh.rank) is_basic[ord_local(eo, sh.world)] = 1;
     if (d >= 0 && d != sh.N) {
       const int64_t dord = ordinal_of(d, sh.N);
-      if (dord % sh.world == sh.rank) is_basic[dord / sh.world] = 0;
+      if (ord_rank(dord, sh.world) == sh.rank) is_basic[ord_local(dord, sh.world)] = 0;
     }
     basis[r] = e;
   };
@@ -1529,7 +1586,7 @@ __global__ __launch_bounds__(256) void k_export_or_zero(
   double v = 0.0;
   if (e >= 0) {
     const int64_t eo = ordinal_of(e, sh.N);
-    if (eo % sh.world == sh.rank) v = T.col(eo / sh.world)[i];
+    if (ord_rank(eo, sh.world) == sh.rank) v = T.col(ord_local(eo, sh.world))[i];
   }
   xbuf[i] = v;
 }
@@ -1610,7 +1667,7 @@ __global__ __launch_bounds__(256) void k_lookahead_select(
   }
   __syncthreads();
   const int64_t e = s_best.gcol;
-  const bool mine = e >= 0 && ordinal_of(e, sh.N) % sh.world == sh.rank;
+  const bool mine = e >= 0 && ord_rank(ordinal_of(e, sh.N), sh.world) == sh.rank;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < sh.lda) xbuf[i] = mine ? xlocal[i] : 0.0;
 }

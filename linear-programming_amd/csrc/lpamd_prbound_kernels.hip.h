@@ -562,7 +562,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_export(
   if (i >= sh.lda) return;
   double v = 0.0;
   if (e >= 0 && i < sh.m) {
-    const int l = (int)(ordinal_of(e, sh.N) / sh.world);      // a local column by construction
+    const int l = ord_local(ordinal_of(e, sh.N), sh.world);      // a local column by construction
     v = chain_apply(T.col(l)[i], j, colp + i, sh.lda, rowp + l, rstride);
   }
   slot_col[i] = v;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void k_export_candidate(
   double v = 0.0;
   if (c.gcol >= 0) {
     const int64_t eo = ordinal_of(c.gcol, sh.N);
-    if (eo % sh.world == sh.rank) v = T.col(eo / sh.world)[i];
+    if (ord_rank(eo, sh.world) == sh.rank) v = T.col(ord_local(eo, sh.world))[i];
   }
   reinterpret_cast<double*>(slot + kSlotHeaderWords)[i] = v;
 }
