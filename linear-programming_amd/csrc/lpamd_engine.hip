@@ -624,7 +624,7 @@ int enqueue_chain_update(lpamd_engine* e) {
     e1 = e->ev[e->ev_used++];
     HIP_TRY(hipEventRecord(e0, e->stream));
   }
-  hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + 255) / 256)), dim3(256), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
+  hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + kListThreads - 1) / kListThreads)), dim3(kListThreads), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
                      e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->deep_batch, e->T,
                      e->ptr_full);
   LP_TRY(check_launch("k_chain_list"));

@@ -526,6 +526,8 @@ __device__ __forceinline__ void pivot_setup_body(
     return;
   }
   // column workgroups: strided over the local columns so that any width fits kMaxPartials workgroups
+  __shared__ int s_cnt[kPartialThreads / kWave];
+  __shared__ int s_base;
   const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
   const int ncl = sh.nloc + 1;
   const int64_t d_now = d_override >= 0 ? d_override : basis[r];   // read before the bookkeeping thread overwrites basis[r]
@@ -552,16 +554,21 @@ __device__ __forceinline__ void pivot_setup_body(
         if (candidate && o > nbv) { nbv = o; nbi = l; }
       }
     }
-    // wave-aggregated append to the active list
+    // append to the active list: one reservation per workgroup (the counter is a single word every workgroup adds to)
     const unsigned long long mask = __ballot(act);
-    if (mask) {
-      const int lane = threadIdx.x & (kWave - 1);
-      const int leader = __ffsll((long long)mask) - 1;
-      int base = 0;
-      if (lane == leader) base = atomicAdd(n_active_ctr, __popcll(mask));
-      base = __shfl(base, leader, kWave);
-      if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_cnt[wave] = __popcll(mask);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int n = 0;
+      for (int w = 0; w < kPartialThreads / kWave; w++) n += s_cnt[w];
+      s_base = n ? atomicAdd(n_active_ctr, n) : 0;
     }
+    __syncthreads();
+    int base = s_base;
+    for (int w = 0; w < wave; w++) base += s_cnt[w];
+    if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
+    __syncthreads();   // s_cnt / s_base are written again in the next round
   }
   block_arg<true, kPartialThreads>(nbv, nbi, s_v, s_i);
   if (threadIdx.x == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; }
@@ -646,11 +653,8 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_setup_small(
     const double ratio = rhs[i] / (-a);
     if (bv > ratio) { bv = ratio; bi = i; }
   }
-  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
-  if (threadIdx.x == 0) s_i[0] = bi;
-  __syncthreads();
-  const int64_t r = s_i[0];
-  __syncthreads();
+  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);   // every thread gets the row
+  const int64_t r = bi;
   if (r < 0) { if (lead) st->status = ST_UNBOUNDED; return; }
   pivot_setup_body(T, sh, c, r, nullptr, n_row_blocks, -1, st, slot ? &st->n_active2 : &st->n_active, false, colp, obj, is_basic, basis,
                    rowp, active, trace, trace_cap, next_pv, next_pi, rhs_next, cand_next, pass, s_v, s_i);
@@ -1172,41 +1176,54 @@ __device__ __forceinline__ int64_t deep_run_index(int k, int s, int depth, int c
 // the row' values of every listed column side by side (rsl_*[k * stride + s] = row'_s of the k-th
 // listed column, zero beyond the chain), which the pass reads as one short run per column.  batch > 0: list_full's
 // runs in the layout of deep_run_index instead, and the address of every column of list_full in ptr_full.
-__global__ __launch_bounds__(256) void k_chain_list(
+constexpr int kListThreads = 1024;   // one reservation in the lists per workgroup: the counters are single words every workgroup adds to
+__global__ __launch_bounds__(kListThreads) void k_chain_list(
     const double* __restrict__ rowp, int64_t rstride, int depth, const ChainStep* __restrict__ steps,
     const PivotState* __restrict__ st, int ncl, PassInfo* __restrict__ pass,
     int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride,
     int batch, Tab T, uint64_t* __restrict__ ptr_full) {
+  constexpr int kWaves = kListThreads / kWave;
+  __shared__ int s_nf[kWaves], s_np[kWaves], s_tot[kWaves];
+  __shared__ int s_bf, s_bp;
   if (st->status != ST_RUNNING) return;
   const int n_steps = chain_steps_done(steps, depth);
   if (blockIdx.x == 0 && threadIdx.x == 0) pass->n_steps = n_steps;
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   int nz = 0;
-  if (l < ncl)
-    for (int s = 0; s < n_steps; s++) nz += rowp[s * rstride + l] != 0.0 ? 1 : 0;
-  const bool full = nz == n_steps, part = nz > 0 && !full;
-  const int lane = threadIdx.x & (kWave - 1);
-  const unsigned long long mf = __ballot(full), mp = __ballot(part);
-  int bf = 0, bp = 0;
-  if (lane == 0) {
-    if (mf) bf = atomicAdd(&pass->n_full, __popcll(mf));
-    if (mp) bp = atomicAdd(&pass->n_part, __popcll(mp));
+  if (l < ncl) {
+#pragma unroll 8
+    for (int s = 0; s < n_steps; s++) nz += rowp[s * rstride + l] != 0.0 ? 1 : 0;   // eight loads per wait
   }
-  bf = __shfl(bf, 0, kWave);
-  bp = __shfl(bp, 0, kWave);
+  const bool full = nz == n_steps, part = nz > 0 && !full;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const unsigned long long mf = __ballot(full), mp = __ballot(part);
   int total = nz;
 #pragma unroll
   for (int off = kWave / 2; off > 0; off >>= 1) total += __shfl_down(total, off, kWave);
-  if (lane == 0 && total) atomicAdd((unsigned long long*)&pass->touched, (unsigned long long)total);
+  if (lane == 0) { s_nf[wave] = __popcll(mf); s_np[wave] = __popcll(mp); s_tot[wave] = total; }
+  __syncthreads();
+  if (threadIdx.x == 0) {      // the workgroup's share of both lists and of the count, reserved with one atomic each
+    int nf = 0, np = 0;
+    long long tot = 0;
+    for (int w = 0; w < kWaves; w++) { nf += s_nf[w]; np += s_np[w]; tot += s_tot[w]; }
+    s_bf = nf ? atomicAdd(&pass->n_full, nf) : 0;
+    s_bp = np ? atomicAdd(&pass->n_part, np) : 0;
+    if (tot) atomicAdd((unsigned long long*)&pass->touched, (unsigned long long)tot);
+  }
+  __syncthreads();
+  int bf = s_bf, bp = s_bp;
+  for (int w = 0; w < wave; w++) { bf += s_nf[w]; bp += s_np[w]; }
   if (full || part) {
     const unsigned long long below = (1ull << lane) - 1ull;
     const int k = full ? bf + __popcll(mf & below) : bp + __popcll(mp & below);
     (full ? list_full : list_part)[k] = l;
     if (full && batch > 0) {   // batches of `batch` columns, the values of one step side by side (k_update_deep)
+#pragma unroll 8
       for (int s = 0; s < stride; s++) rsl_full[deep_run_index(k, s, stride, batch)] = s < n_steps ? rowp[s * rstride + l] : 0.0;
       ptr_full[k] = (uint64_t)T.col(l);   // the addresses of a batch's columns: one scalar load in the pass
     } else {
       double* __restrict__ out = (full ? rsl_full : rsl_part) + (int64_t)k * stride;
+#pragma unroll 8
       for (int s = 0; s < stride; s++) out[s] = s < n_steps ? rowp[s * rstride + l] : 0.0;
     }
   }

@@ -82,3 +82,15 @@ def test_device_entry_points_fail_loudly_without_gpu():
         lp.TableauEngine(4, 8)
     with pytest.raises(lp.LpamdError, match="no HIP device"):
         lp.RevisedTableauEngine(4, 8)
+
+
+def test_create_rejects_shapes_beyond_31_bits():
+    """Column ids and rows are kept in 32 bits inside the set-up kernels: a larger shape is refused at create,
+    before any device is touched."""
+    lp = lpamd_pkg()
+    L = lp.library()
+    h = ctypes.c_void_p()
+    for m, N, world in ((4, 1 << 31, 4), ((1 << 31) + 5, 8, 1)):   # 2^29 columns per rank pass the per-rank limit
+        rc = L.lpamd_create(ctypes.byref(h), m, N, 0, world, None)
+        assert rc != 0 and not h.value
+        assert b"31 bits" in L.lpamd_last_error()

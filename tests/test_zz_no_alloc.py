@@ -73,6 +73,20 @@ def test_noalloc_ratio_test_edge_cases(lpamd):
     # no eligible row: unbounded
     r, ratio = _noalloc(eng_mod, np.array([1.0, 0.0, 5e-7, 2.0, 0.0]), rhs)
     assert (r, ratio) == (-1, 0.0)
+    # the reductions run on an integer image of (ratio, row): negative ratios, both zeros (equal: the lower row wins),
+    # denormals and ties far apart (different wavefronts and workgroups) must order as the doubles do
+    assert _noalloc(eng_mod, np.array([-1.0, -1.0, -1.0, -1.0]), np.array([1.0, -2.0, -3.0, -3.0])) == (2, -3.0)
+    assert _noalloc(eng_mod, np.array([-1.0, -1.0, -1.0]), np.array([0.0, -0.0, 3.0])) == (0, 0.0)
+    assert _noalloc(eng_mod, np.array([-1.0, -1.0, -1.0]), np.array([-0.0, 0.0, 3.0])) == (0, 0.0)
+    assert _noalloc(eng_mod, np.array([-1.0, -1.0]), np.array([1e-310, 5e-324])) == (1, 5e-324)
+    m = 70000
+    col, rhs = np.full(m, -1.0), np.full(m, 7.0)
+    rhs[[65, 300, 66000]] = 2.5                      # equal minima in three wavefronts of two workgroups
+    assert _noalloc(eng_mod, col, rhs) == (65, 2.5)
+    rhs[65] = 7.0
+    assert _noalloc(eng_mod, col, rhs) == (300, 2.5)
+    rhs[300] = np.nextafter(2.5, 3.0)
+    assert _noalloc(eng_mod, col, rhs) == (66000, 2.5)
     # one row, on an explicit stream
     s = torch.cuda.Stream()
     assert _noalloc(eng_mod, np.array([-4.0]), np.array([2.0]), s.cuda_stream) == (0, 0.5)
