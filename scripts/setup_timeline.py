@@ -37,11 +37,11 @@ L.lpamd_dbg_clock.restype = ctypes.c_int
 assert L.lpamd_dbg_clock(buf) == 0
 t = lambda j, who, cp: buf[(j * 4 + who) * 8 + cp]
 print("config %s shard_of %d depth %d; microseconds after the entry of the step's first set-up kernel" % (config, shard_of, depth))
-print(" j | ratio: first load | status known | ... | loop end  wave_arg  barrier  end")
+print(" j | k_chain_ratio: first load back | gating state and pricing partials back")
 for j in range(1, depth):
     base = t(j, 0, 0)
     if base:
-        print("%2d | %5.2f | %5.2f | ... | %5.2f %5.2f %5.2f %5.2f" % (j, (t(j, 0, 7) - base) / 100.0, (t(j, 0, 4) - base) / 100.0, (t(j, 0, 2) - base) / 100.0, (t(j, 0, 5) - base) / 100.0, (t(j, 0, 6) - base) / 100.0, (t(j, 0, 3) - base) / 100.0))
+        print("%2d | %5.2f | %5.2f" % (j, (t(j, 0, 7) - base) / 100.0, (t(j, 0, 4) - base) / 100.0))
 print(" j | ratio: gate+fold  loop  end | finalize: entry  r2  a2  rows_end | cols: entry r2 a2 d2 loop end | last wg: entry loop_end | next entry")
 for j in range(1, depth):
     base = t(j, 0, 0) or t(j, 2, 0)
