@@ -129,14 +129,15 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
   // (a) eight threads per segment, all loads of a thread in flight together.  Up to 256 rows per segment (m <= 32768)
   // a thread's 32 values stay in registers and the rows that meet the threshold are picked from them in (b); longer
   // columns are read a second time.
-  const int n_seg = (int)min((int64_t)kPrbSegments, sh.m);
-  const int64_t seg = (sh.m + n_seg - 1) / n_seg;
+  const int m32 = (int)sh.m;     // rows fit 31 bits (checked at create): 32-bit index arithmetic, a third of the instructions
+  const int n_seg = min(kPrbSegments, m32);
+  const int seg = (m32 + n_seg - 1) / n_seg;
   constexpr int kPerSeg = kPrbRowThreads / kPrbSegments;
   constexpr int kKeep = 32;    // values a thread keeps
   constexpr int kLoads = 16;   // loads in flight per thread otherwise (unconditional: the index is clamped, the value masked)
   constexpr bool keep = kKeepRows;
   const int sidx = tid / kPerSeg, sub = tid % kPerSeg;
-  const int64_t i0 = (int64_t)sidx * seg + sub, i1 = sidx < n_seg ? min((int64_t)(sidx + 1) * seg, sh.m) : 0;
+  const int i0 = sidx * seg + sub, i1 = sidx < n_seg ? min((sidx + 1) * seg, m32) : 0;
   double kept[kKeepRows ? kKeep : 1];
   double mymin = DBL_MAX;
   if constexpr (keep) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
       for (int u = 0; u < kKeep; u++) mymin = fmin(mymin, kept[u]);
     }
   } else if (sidx < n_seg) {
-    for (int64_t i = i0; i < i1; i += kPerSeg * kLoads) {
+    for (int i = i0; i < i1; i += kPerSeg * kLoads) {
       double v[kLoads];
 #pragma unroll
       for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPerSeg, i1 - 1)];
@@ -163,15 +164,20 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
   }
   __syncthreads();
   // (b) the threshold, then the rows that meet it
-  if (tid < n_seg) {
-    const double mine = s_seg[tid];
+  {   // rank of every segment minimum among the minima: the eight threads of a segment count a share each
+    const double mine = sidx < n_seg ? s_seg[sidx] : 0.0;
     int rank = 0;
-#pragma unroll 16
-    for (int q = 0; q < n_seg; q++) {
-      const double other = s_seg[q];
-      rank += (other < mine || (other == mine && q < tid)) ? 1 : 0;
+    if (sidx < n_seg) {
+#pragma unroll 4
+      for (int q = sub; q < n_seg; q += kPerSeg) {
+        const double other = s_seg[q];
+        rank += (other < mine || (other == mine && q < sidx)) ? 1 : 0;
+      }
     }
-    if (rank == max_rows - 1) s_tau = mine;
+    rank += dpp_i32<kDppXor1>(rank);
+    rank += dpp_i32<kDppXor2>(rank);
+    rank += dpp_i32<kDppHalfMirror>(rank);     // the eight lanes of a segment sit in one half row
+    if (sub == 0 && sidx < n_seg && rank == max_rows - 1) s_tau = mine;
   }
   __syncthreads();
   const double tau = s_tau;
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     if (mymin <= tau) {        // a few threads only
 #pragma unroll
       for (int u = 0; u < kKeep; u++) {
-        const int64_t i = i0 + u * kPerSeg;
+        const int i = i0 + u * kPerSeg;
         if (i < i1 && kept[u] <= tau) {
           const int k = atomicAdd(&s_ncoll, 1);
           if (k < kPrbCollect) { s_crow[k] = (int32_t)i; s_cb[k] = kept[u]; }
@@ -187,13 +193,13 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
       }
     }
   } else {
-    for (int64_t i = tid; i < sh.m; i += kPrbRowThreads * kLoads) {
+    for (int i = tid; i < m32; i += kPrbRowThreads * kLoads) {
       double v[kLoads];
 #pragma unroll
-      for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPrbRowThreads, sh.m - 1)];
+      for (int u = 0; u < kLoads; u++) v[u] = rhs[min(i + u * kPrbRowThreads, m32 - 1)];
 #pragma unroll
       for (int u = 0; u < kLoads; u++) {
-        if (v[u] <= tau && i + u * kPrbRowThreads < sh.m) {
+        if (v[u] <= tau && i + u * kPrbRowThreads < m32) {
           const int k = atomicAdd(&s_ncoll, 1);
           if (k < kPrbCollect) { s_crow[k] = (int32_t)(i + u * kPrbRowThreads); s_cb[k] = v[u]; }
         }
@@ -240,10 +246,13 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     for (int q = 0; q < kPrbRows; q++)
       if (s_slot_row[q] == (int32_t)mine) my_slot = q;
   const bool hit = lane < n_rows && my_slot >= 0, miss = lane < n_rows && my_slot < 0;
-  const unsigned long long hits = __ballot(hit);
-  unsigned used = 0;
-  for (int q = 0; q < n_rows; q++)
-    if ((hits >> q) & 1ull) used |= 1u << __shfl(my_slot, q, kWave);
+  unsigned used = hit ? 1u << my_slot : 0u;      // slots the rows of R occupy already: OR over the wavefront
+  used |= (unsigned)dpp_i32<kDppXor1>((int)used);
+  used |= (unsigned)dpp_i32<kDppXor2>((int)used);
+  used |= (unsigned)dpp_i32<kDppHalfMirror>((int)used);
+  used |= (unsigned)dpp_i32<kDppMirror>((int)used);
+  used = (unsigned)__builtin_amdgcn_readlane((int)used, 0) | (unsigned)__builtin_amdgcn_readlane((int)used, 16) |
+         (unsigned)__builtin_amdgcn_readlane((int)used, 32) | (unsigned)__builtin_amdgcn_readlane((int)used, 48);
   const unsigned long long missing = __ballot(miss);
   const int nth = __popcll(missing & ((1ull << lane) - 1ull));
   if (miss) {
