@@ -1633,28 +1633,34 @@ __global__ __launch_bounds__(kPartialThreads) void k_export_lookahead(
     const double* __restrict__ rhsv, double* __restrict__ rpart_v, int64_t* __restrict__ rpart_i) {
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
-  if (st->status != ST_RUNNING) return;
-  double ce;
-  int64_t l;
-  fold_partials<true, kPartialThreads>(pv, pi, n_price_part, ce, l, s_v, s_i);
-  if (kRatio && st->iter >= st->max_iter) l = -1;
+  // requested before the first wait: the gating state, the step records, this thread's share of the pricing partials
+  // and its entry of the right-hand side (a round trip each if they were asked for one after the other)
+  const int32_t status = st->status;
+  const int64_t iter = st->iter, max_iter = st->max_iter;
+  const int n = pending > 0 ? chain_steps_done(steps, pending) : 0;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double* __restrict__ rhs = n == 0 ? T.col(sh.nloc) : rhsv + (int64_t)(n - 1) * sh.lda;
+  const double rhs_i = (kRatio && i < sh.m) ? rhs[i] : 0.0;
+  double ce = -DBL_MAX;
+  int64_t l = -1;
+  fold_share<true, kPartialThreads>(pv, pi, n_price_part, ce, l);
+  if (status != ST_RUNNING) return;
+  block_arg<true, kPartialThreads>(ce, l, s_v, s_i);
+  if (kRatio && iter >= max_iter) l = -1;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     Candidate c;
     c.key = ce; c.ce = ce; c.row = -1;
     c.gcol = l < 0 ? -1 : gcol_of(l * sh.world + sh.rank, sh.N);
     *cand_local = c;
   }
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (!kRatio && i >= sh.lda) return;
   double v = 0.0;
-  const int n = pending > 0 ? chain_steps_done(steps, pending) : 0;
   if (l >= 0 && i < sh.m) v = chain_apply(T.col(l)[i], n, colp + i, sh.lda, rowp + l, rstride);   // the update leaves columns with row' == 0 alone
   if (i < sh.lda) xlocal[i] = v;
   if (kRatio) {
-    const double* __restrict__ rhs = n == 0 ? T.col(sh.nloc) : rhsv + (int64_t)(n - 1) * sh.lda;
     double bv = DBL_MAX;
     int64_t bi = -1;
-    if (l >= 0 && i < sh.m && (float)v <= -1e-6f) { bv = rhs[i] / (-v); bi = i; }
+    if (l >= 0 && i < sh.m && (float)v <= -1e-6f) { bv = rhs_i / (-v); bi = i; }
     block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
     if (threadIdx.x == 0) { rpart_v[blockIdx.x] = bv; rpart_i[blockIdx.x] = bi; }
   }
