@@ -36,13 +36,20 @@ $(BINDIR)/lp_host_selftest: $(HOST_SRCS) $(wildcard $(CSRC)/host/*.h) $(LIBDIR)/
 
 oracle:
 	$(MAKE) -C oracle
+	gcc -O1 -g -shared -fPIC -o tests/native/libsegvinfo.so tests/native/segv_info.c   # test-only: what a fatal signal says (tests/conftest.py)
 
 # experiments only: the engine with wall-clock checkpoints in the set-up kernels (scripts/setup_timeline.py)
 dbg-clock:
 	@mkdir -p bin_scratch
 	$(HIPCC) $(HIPFLAGS) -DLPAMD_DBG_CLOCK -shared -o bin_scratch/liblpamd_dbgclock.so $(CSRC)/lpamd_engine.hip
 
+# experiments only: the engine with index checks in the kernels (tests/conftest.py reads the counters after every test
+# when LPAMD_LIBRARY points at this build)
+dbg-checks:
+	@mkdir -p bin_scratch
+	$(HIPCC) $(HIPFLAGS) -DLPAMD_DEVICE_CHECKS -shared -o bin_scratch/liblpamd_checks.so $(CSRC)/lpamd_engine.hip
+
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) build
 	$(MAKE) -C oracle clean
-.PHONY: all engine host host-bins oracle clean dbg-clock
+.PHONY: all engine host host-bins oracle clean dbg-clock dbg-checks

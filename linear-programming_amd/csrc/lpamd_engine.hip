@@ -1701,3 +1701,14 @@ extern "C" int lpamd_dbg_clock(unsigned long long* out) {
   return LPAMD_OK;
 }
 #endif
+
+#ifdef LPAMD_DEVICE_CHECKS
+// experiments only: how often each index check of the kernels failed since the last call (32 counters, cleared by the call)
+extern "C" int lpamd_dbg_check_failures(unsigned int* out) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(lpamd::g_check_fail), sizeof(unsigned int) * 32));
+  unsigned int zero[32] = {0};
+  HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(lpamd::g_check_fail), zero, sizeof(zero)));
+  return LPAMD_OK;
+}
+#endif

@@ -104,6 +104,15 @@ __device__ unsigned long long g_dbg_clock[kMaxChain][4][8];
 #define LPAMD_CLKR_FLUSH(j, who, cond) do { } while (0)
 #endif
 
+// Index checks of the kernels (experiments only, -DLPAMD_DEVICE_CHECKS; `make dbg-checks`): a violated bound is counted
+// per check id instead of trapping, read back with lpamd_dbg_check_failures.  Off in the product build.
+#ifdef LPAMD_DEVICE_CHECKS
+__device__ unsigned int g_check_fail[32];
+#define LPAMD_CHECK(id, cond) do { if (!(cond)) atomicAdd(&g_check_fail[id], 1u); } while (0)
+#else
+#define LPAMD_CHECK(id, cond) do { } while (0)
+#endif
+
 // reference base.h:61-66: the predicates take float, so the double is narrowed first.
 __device__ __forceinline__ bool is_pos(double x) { return (float)x >= 1e-6f; }
 __device__ __forceinline__ bool is_neg(double x) { return (float)x <= -1e-6f; }
@@ -510,6 +519,7 @@ __device__ __forceinline__ void pivot_setup_body(
     double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, PassInfo* __restrict__ pass, double* s_v, int64_t* s_i) {
   const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
   const double* __restrict__ col = xcol ? xcol : T.col(ord_local(eo, sh.world));
+  LPAMD_CHECK(0, r >= 0 && r < sh.m && eo >= 0 && eo <= sh.N);
   const double a = col[r];
   const double f = -1.0 / a;                         // lp_simplex_tableau.cc:40
   const double g = __dmul_rn(c.ce, f);               // lp_simplex_tableau.cc:34-35
@@ -567,6 +577,7 @@ __device__ __forceinline__ void pivot_setup_body(
     __syncthreads();
     int base = s_base;
     for (int w = 0; w < wave; w++) base += s_cnt[w];
+    LPAMD_CHECK(1, !act || (base >= 0 && base + __popcll(mask & ((1ull << lane) - 1ull)) < ncl));
     if (act) active[base + __popcll(mask & ((1ull << lane) - 1ull))] = l;
     __syncthreads();   // s_cnt / s_base are written again in the next round
   }
@@ -582,6 +593,7 @@ __device__ __forceinline__ void pivot_setup_body(
     st->l_e = l_e; st->l_d = l_d;
     pass->n_steps = 0; pass->n_full = 0; pass->n_part = 0; pass->touched = 0;   // filled by k_chain_list when the pass is a chain
     const int64_t it = st->iter;
+    LPAMD_CHECK(2, it >= 0 && cb == 0);
     if (it < trace_cap) { trace[2 * it] = e; trace[2 * it + 1] = r; }
     if (bump_iter) st->iter = it + 1;
   }
@@ -752,6 +764,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   const int64_t stamp = st->iter;
   for (int k = blockIdx.x; k < n_active; k += gridDim.x) {
     const int l = active[k];
+    LPAMD_CHECK(3, n_active <= sh.nloc + 1 && l >= 0 && l <= sh.nloc);
     const double rj = rowp[l];
     double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l));
     const bool price = kFusePR && l < sh.nloc && cand_next[l] != 0;   // uniform over the workgroup
@@ -912,6 +925,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_ratio(
     if (lead) { steps[j].e = gcol_of(l * sh.world + sh.rank, sh.N); steps[j].ce = ce; }
   }
   LPAMD_CLKR(1, blockIdx.x == 0);
+  LPAMD_CHECK(4, j >= 1 && j < depth && depth <= kMaxChain && l >= 0 && l < sh.nloc);
   const double* __restrict__ col = T.col(l);
   double bv = DBL_MAX;
   int64_t bi = -1;
@@ -1073,6 +1087,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     return (ord_rank(o, sh.world) == sh.rank) ? ord_local(o, sh.world) : -1;
   };
   const int l_e2 = local_id(e2);
+  LPAMD_CHECK(5, j >= 1 && j < kMaxChain && r2 < sh.m && e2 >= 0 && e2 <= sh.N + 1 && e2 != sh.N && l_e2 < sh.nloc);
   if (kRebuild && l_e2 < 0) return;   // not reachable: a rebuilt column is a local one
   const double* __restrict__ ecol = kRebuild ? T.col(l_e2) : colv;
   // ---- second round of requests: everything that hangs on the pivot row
@@ -1116,6 +1131,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     }
   }
   const int l_d2 = local_id(d2);
+  LPAMD_CHECK(6, d2 >= -1 && d2 <= sh.N + 1 && l_d2 < sh.nloc);
   LPAMD_CLK(j, 2, 3, cb == 0 && l_d2 != -7);
   double nbv = -DBL_MAX;
   int64_t nbi = -1;
@@ -1149,6 +1165,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     steps[j].l_in = l_e2; steps[j].l_out = l_d2;
     steps[j].done = 1;
     const int64_t it = st->iter;
+    LPAMD_CHECK(7, it >= 0);
     if (it < trace_cap) { trace[2 * it] = e2; trace[2 * it + 1] = r2; }
     st->iter = it + 1;
   }
@@ -1216,6 +1233,7 @@ __global__ __launch_bounds__(kListThreads) void k_chain_list(
   if (full || part) {
     const unsigned long long below = (1ull << lane) - 1ull;
     const int k = full ? bf + __popcll(mf & below) : bp + __popcll(mp & below);
+    LPAMD_CHECK(8, k >= 0 && k < ncl && n_steps >= 1 && n_steps <= stride && stride <= kMaxChain);
     (full ? list_full : list_part)[k] = l;
     if (full && batch > 0) {   // batches of `batch` columns, the values of one step side by side (k_update_deep)
 #pragma unroll 8
@@ -1233,6 +1251,7 @@ __global__ __launch_bounds__(kListThreads) void k_chain_list(
 __device__ __forceinline__ void chain_bookkeeping(PivotState* st, ChainStep* steps, const PassInfo& pass, const Shape& sh,
                                                   uint8_t* is_basic, int64_t* basis) {
   auto flip = [&](int64_t e, int64_t d, int64_t r) {
+    LPAMD_CHECK(9, e >= 0 && e <= sh.N + 1 && e != sh.N && r >= 0 && r < sh.m && d >= -1 && d <= sh.N + 1);
     const int64_t eo = ordinal_of(e, sh.N);
     if (ord_rank(eo, sh.world) == sh.rank) is_basic[ord_local(eo, sh.world)] = 1;
     if (d >= 0 && d != sh.N) {
@@ -1281,6 +1300,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_chain(
   for (int k = blockIdx.x; k < n_list; k += gridDim.x) {
     const bool in_full = k < pass.n_full;
     const int l = in_full ? list_full[k] : list_part[k - pass.n_full];
+    LPAMD_CHECK(10, l >= 0 && l <= sh.nloc && n_list <= sh.nloc + 1 && pass.n_steps <= stride);
     const double* __restrict__ rs = in_full ? rsl_full + (int64_t)k * stride : rsl_part + (int64_t)(k - pass.n_full) * stride;
     double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l));
     int v = threadIdx.x;
@@ -1357,6 +1377,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
       double2 t[kC][kR];
 #pragma unroll
       for (int u = 0; u < kC; u++) {
+        LPAMD_CHECK(11, list_full[k0 + u] >= 0 && list_full[k0 + u] <= sh.nloc && stride >= kK);
         p[u] = reinterpret_cast<double2*>(T.col(list_full[k0 + u])) + v0;
 #pragma unroll
         for (int r = 0; r < kR; r++) t[u][r] = ld16<kNT>(p[u] + r * kUpdateThreads);
@@ -1408,6 +1429,7 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update_slab(
       if (k >= n_list) break;
       const bool in_full = k < pass.n_full;
       const int l = in_full ? list_full[k] : list_part[k - pass.n_full];
+      LPAMD_CHECK(12, l >= 0 && l <= sh.nloc && n_list <= sh.nloc + 1 && n_steps <= kK && n_steps <= stride && (int64_t)(v0 + (kR - 1) * kUpdateThreads) < lda / 2);
       const double* __restrict__ rs = in_full ? rsl_full + (int64_t)k * stride : rsl_part + (int64_t)(k - pass.n_full) * stride;
       double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l)) + v0;
       double2 w[kR];
@@ -1555,6 +1577,7 @@ __global__ __launch_bounds__(kDeepThreads, kC == 4 ? 4 : 2) void k_update_deep(
   for (int k = n_batches * kC + stream; k < n_list; k += n_streams) {
     const bool in_full = k < pass.n_full;
     const int l = in_full ? list_full[k] : list_part[k - pass.n_full];
+    LPAMD_CHECK(13, l >= 0 && l <= sh.nloc && n_list <= sh.nloc + 1 && n_steps <= depth && (int64_t)v0 < lda / 2);
     double2* __restrict__ p = reinterpret_cast<double2*>(T.col(l)) + v0;
     double2 w = ld16<kNT>(p);
     for (int s = 0; s < n_steps; s++) {
