@@ -4,6 +4,7 @@
 // PivotState back once per batch of pivots).
 #include "lpamd_kernels.hip.h"
 #include "lpamd_prbound_kernels.hip.h"
+#include "lpamd_fused_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -76,6 +77,15 @@ struct lpamd_engine {
   int32_t deep_batch = 0;       // > 0: k_update_deep with that many columns per batch (chains longer than 16)
   int32_t deep_grid = 0;        // workgroups of k_update_deep (0: sized from the shard, see launch_deep)
   int64_t rstride = 0;
+  // steps 1.. of a MAX_COST chain set up by one launch of resident workgroups (k_chain_fused; one GPU)
+  bool fused = false;
+  bool fused_pending = false;   // the pivot count lacks the fused steps until k_chain_list has run
+  int32_t fused_rows = 0, fused_cols = 0;   // row / column workgroups
+  int32_t fused_threads = 256;              // threads per workgroup (256, 512 or 1024)
+  bool fused_reg = false;                   // one row / column per thread, its history in registers
+  uint64_t* rec_ratio = nullptr;  // [2 parities][kFusedReplicas copies][fused_region_words(fused_rows, kFusedRatioWords)]
+  uint64_t* rec_price = nullptr;  // [2][kFusedReplicas][fused_region_words(fused_cols, kFusedPriceWords)]
+  uint32_t fused_epoch = 0;
   ChainStep* steps = nullptr;   // [kMaxChain]
   double* colv = nullptr;       // entering column of the next step as the steps before it will leave it
   // MAX_REDUCTION pricing from bounds (lpamd_prbound_kernels.hip.h): lets those pivots chain as well
@@ -225,11 +235,19 @@ int placement_probe_ms(lpamd_engine* e, double* a, double* b, size_t bytes_per_s
 }
 
 int allocate_tableau(lpamd_engine* e) {
-  e->T.lda = e->sh.lda;
+  // Column pitch of the tableau: the rows rounded up (LPAMD_LDA_PAD=<rows>: that many more; experiments).  The kernels that
+  // set a pivot up read ONE row of the column-major tableau, a sector of every column, and with columns a large power of
+  // two apart those sectors fall on few memory channels: at m=32768 n=65536 the gather of 98 k sectors takes 1.6 .. 4.7 us,
+  // 2.7 .. 3.1 us with the pitch 4 KiB longer.  The pass kernel, however, streams 0.8 % slower over columns that are not
+  // 256 KiB apart (3.7 % at m=4096 n=8192), which costs more than the gathers gain, so the default is no padding.  Padding
+  // rows are never read or written: every loop over a column runs to sh.lda.
+  int64_t pad = 0;
+  if (const char* env = getenv("LPAMD_LDA_PAD")) pad = round_up(std::max(0, atoi(env)), kSlabRows);
+  e->T.lda = e->sh.lda + pad;
   e->half_cols[0] = (e->ncl + 1) / 2;
   e->half_cols[1] = e->ncl / 2;
   size_t bytes[2];
-  for (int h = 0; h < 2; h++) bytes[h] = sizeof(double) * (size_t)e->sh.lda * (size_t)e->half_cols[h];
+  for (int h = 0; h < 2; h++) bytes[h] = sizeof(double) * (size_t)e->T.lda * (size_t)e->half_cols[h];
   hipError_t err = hipMalloc(&e->T.half[0], bytes[0]);
   if (err != hipSuccess)
     return set_err(LPAMD_E_HIP, "hipMalloc of %.2f GB for the tableau shard failed: %s", bytes[0] / 1e9, hipGetErrorString(err));
@@ -606,6 +624,27 @@ int prb_shard_setup(lpamd_engine* e, const Candidate* cand, const double* xbuf) 
 
 // The further pivots of a pass and the pass itself, for the pivot that k_pivot_finalize has just set up.
 int enqueue_chain_tail(lpamd_engine* e, int depth) {
+  if (e->fused && depth > 1) {
+    e->fused_epoch = (e->fused_epoch + 1) & 0xFFFFFFu;
+    if (e->fused_epoch == 0) {   // the launch number wrapped: no record of an old launch may carry a tag that comes round again
+      HIP_TRY(hipMemsetAsync(e->rec_ratio, 0, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_rows, kFusedRatioWords), e->stream));
+      HIP_TRY(hipMemsetAsync(e->rec_price, 0, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_cols, kFusedPriceWords), e->stream));
+      e->fused_epoch = 1;
+    }
+#define LPAMD_LAUNCH_FUSED(THREADS, REG, HIST)                                                                                        \
+  hipLaunchKernelGGL((k_chain_fused<THREADS, REG, HIST>), dim3(e->fused_rows + e->fused_cols), dim3(THREADS), 0, e->stream, e->T, e->sh, e->st, \
+                     e->steps, depth, e->fused_rows, e->part_v, e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->rhs_next,     \
+                     e->colv, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->rec_ratio, e->rec_price, e->fused_epoch)
+    const bool h24 = e->chain_depth <= 24;
+    if (e->fused_threads == 1024) LPAMD_LAUNCH_FUSED(1024, false, 32);
+    else if (e->fused_threads == 512) { if (!e->fused_reg) LPAMD_LAUNCH_FUSED(512, false, 32); else if (h24) LPAMD_LAUNCH_FUSED(512, true, 24); else LPAMD_LAUNCH_FUSED(512, true, 32); }
+    else { if (!e->fused_reg) LPAMD_LAUNCH_FUSED(256, false, 32); else if (h24) LPAMD_LAUNCH_FUSED(256, true, 24); else LPAMD_LAUNCH_FUSED(256, true, 32); }
+#undef LPAMD_LAUNCH_FUSED
+    LP_TRY(check_launch("k_chain_fused"));
+    e->price_partials_fresh = true;
+    e->fused_pending = true;
+    return enqueue_chain_update(e);
+  }
   for (int j = 1; j < depth; j++) LP_TRY(enqueue_chain_step(e, j, nullptr, nullptr));
   return enqueue_chain_update(e);
 }
@@ -626,7 +665,8 @@ int enqueue_chain_update(lpamd_engine* e) {
   }
   hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + kListThreads - 1) / kListThreads)), dim3(kListThreads), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
                      e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->deep_batch, e->T,
-                     e->ptr_full);
+                     e->ptr_full, e->fused_pending ? 1 : 0);
+  e->fused_pending = false;
   LP_TRY(check_launch("k_chain_list"));
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
   const int grid = e->update_grid;
@@ -808,7 +848,6 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->sh.m = m;
   e->sh.N = N;
   e->sh.lda = round_up(m, kSlabRows);
-  if (const char* env = getenv("LPAMD_LDA_PAD")) e->sh.lda += round_up(std::max(0, atoi(env)), kSlabRows);
   e->sh.nloc = (int32_t)nloc;
   e->sh.rank = rank;
   e->sh.world = world;
@@ -891,7 +930,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
   HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
-  HIP_TRY(hipMalloc(&e->colv, sizeof(double) * e->sh.lda));
+  HIP_TRY(hipMalloc(&e->colv, sizeof(double) * 2 * e->sh.lda));   // k_chain_fused keeps two copies that take turns
   // MAX_REDUCTION prices from bounds wherever pivots chain
   e->pr_bounds = e->chain_depth > 1;
   if (const char* env = getenv("LPAMD_PR_BOUNDS")) e->pr_bounds = e->pr_bounds && atoi(env) != 0;
@@ -912,6 +951,51 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->prb_escore, sizeof(double) * e->ncl));
     HIP_TRY(hipMalloc(&e->prb_erow, sizeof(int64_t) * e->ncl));
   }
+  // Steps 1.. of a MAX_COST chain in one launch (k_chain_fused): one GPU, chains only.  Preferred shape: one row / one column
+  // per thread (history in registers) with the smallest workgroups that keep the grid within 512 workgroups, which the
+  // chip holds at once with room to spare; shards too wide for that give a thread several columns (history from memory).
+  e->fused = world == 1 && e->chain_depth > 1;
+  if (const char* env = getenv("LPAMD_FUSED")) e->fused = e->fused && atoi(env) != 0;
+  if (e->fused) {
+    // limits of the kernel: at most 128 row workgroups (their records are folded by one wavefront, two per lane), at most two
+    // column workgroups per thread of a workgroup (their records are folded by a whole row workgroup), 32 columns per thread
+    auto blocks = [](int64_t items, int64_t per) { return (items + per - 1) / per; };
+    int threads = 256;
+    while (threads < 1024 && (blocks(m, threads) > 128 || blocks(m, threads) + blocks(e->ncl, threads) > 520)) threads *= 2;
+    if (const char* env = getenv("LPAMD_FUSED_THREADS")) { const int t = atoi(env); if (t == 256 || t == 512 || t == 1024) threads = t; }
+    e->fused_threads = threads;
+    e->fused_rows = (int32_t)std::min<int64_t>(128, blocks(m, threads));
+    e->fused_cols = (int32_t)std::min<int64_t>(392, blocks(e->ncl, threads));
+    if (const char* env = getenv("LPAMD_FUSED_ROWS")) e->fused_rows = std::max(1, std::min(128, atoi(env)));
+    if (const char* env = getenv("LPAMD_FUSED_COLS")) e->fused_cols = std::max(1, std::min(2 * threads, atoi(env)));
+    e->fused_reg = threads < 1024 && (int64_t)e->fused_rows * threads >= m && (int64_t)e->fused_cols * threads >= e->ncl;   // 1024 threads leave 128 registers each: the history would spill
+    if (const char* env = getenv("LPAMD_FUSED_REG")) e->fused_reg = e->fused_reg && atoi(env) != 0;
+    // Every workgroup of the grid must be resident at the same time (they wait for each other): the grid may take three
+    // quarters of what the device holds of this kernel; otherwise the leaner variant (history from memory), and if that does
+    // not fit either, the step-by-step kernels.
+    auto capacity = [&](bool reg) -> int64_t {
+      int per_cu = 0, cus = 0;
+      hipError_t err = hipSuccess;
+#define LPAMD_OCC(THREADS, REG, HIST) err = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_chain_fused<THREADS, REG, HIST>, THREADS, 0)
+      const bool h24 = e->chain_depth <= 24;
+      if (threads == 1024) LPAMD_OCC(1024, false, 32);
+      else if (threads == 512) { if (!reg) LPAMD_OCC(512, false, 32); else if (h24) LPAMD_OCC(512, true, 24); else LPAMD_OCC(512, true, 32); }
+      else { if (!reg) LPAMD_OCC(256, false, 32); else if (h24) LPAMD_OCC(256, true, 24); else LPAMD_OCC(256, true, 32); }
+#undef LPAMD_OCC
+      if (err != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+      return (int64_t)per_cu * cus;
+    };
+    const int64_t grid = e->fused_rows + e->fused_cols;
+    if (e->fused_reg && grid * 4 > capacity(true) * 3) e->fused_reg = false;
+    if (!e->fused_reg && grid * 4 > capacity(false) * 3) e->fused = false;
+    if (blocks(e->ncl, (int64_t)e->fused_cols * threads) > 32) e->fused = false;
+  }
+  if (e->fused) {
+    HIP_TRY(hipMalloc(&e->rec_ratio, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_rows, kFusedRatioWords)));
+    HIP_TRY(hipMalloc(&e->rec_price, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_cols, kFusedPriceWords)));
+    HIP_TRY(hipMemsetAsync(e->rec_ratio, 0, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_rows, kFusedRatioWords), e->stream));
+    HIP_TRY(hipMemsetAsync(e->rec_price, 0, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_cols, kFusedPriceWords), e->stream));
+  }
   HIP_TRY(hipMalloc(&e->pass, sizeof(PassInfo)));
   HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
   if (e->chain_depth > 1) {
@@ -921,7 +1005,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->chain_depth));
     HIP_TRY(hipMalloc(&e->ptr_full, sizeof(uint64_t) * (size_t)(e->ncl + 8)));
   }
-  HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * e->sh.lda, e->stream));    // rows beyond m stay zero
+  HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * 2 * e->sh.lda, e->stream));    // rows beyond m stay zero
   HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
   HIP_TRY(hipMalloc(&e->cand_la, sizeof(Candidate)));
   HIP_TRY(hipMemsetAsync(e->cand_la, 0xFF, sizeof(Candidate), e->stream));   // gcol = -1: no candidate
@@ -947,7 +1031,7 @@ int lpamd_destroy(lpamd_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
   void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->ptr_full,
-                  e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
+                  e->rec_ratio, e->rec_price, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -961,11 +1045,11 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
   const Shape& sh = e->sh;
   if (!T || !obj || !is_basic || ld < sh.m) return set_err(LPAMD_E_ARG, "upload: null buffer or ld < m");
   std::vector<double> hT[2], hobj(e->ncl, 0.0);
-  for (int h = 0; h < 2; h++) hT[h].assign((size_t)sh.lda * e->half_cols[h], 0.0);
+  for (int h = 0; h < 2; h++) hT[h].assign((size_t)e->T.lda * e->half_cols[h], 0.0);
   std::vector<uint8_t> hb(e->ncl, 0);
   for (int64_t l = 0; l < e->ncl; l++) {
     const int64_t g = global_of(e, l);
-    std::memcpy(&hT[l & 1][(size_t)(l >> 1) * sh.lda], T + g * ld, sizeof(double) * sh.m);
+    std::memcpy(&hT[l & 1][(size_t)(l >> 1) * e->T.lda], T + g * ld, sizeof(double) * sh.m);
     hobj[l] = obj[g];
     hb[l] = (g == sh.N || g == sh.N + 1) ? 0 : (is_basic[g] ? 1 : 0);
   }
@@ -1014,10 +1098,10 @@ int lpamd_download(const lpamd_engine* e, double* T, int64_t ld, double* obj, ui
     if (ld < sh.m) return set_err(LPAMD_E_ARG, "download: ld < m");
     for (int h = 0; h < 2; h++) {
       if (e->half_cols[h] == 0) continue;
-      std::vector<double> hT((size_t)sh.lda * e->half_cols[h]);
+      std::vector<double> hT((size_t)e->T.lda * e->half_cols[h]);
       LP_TRY(read_local(e, e->T.half[h], hT.data(), sizeof(double) * hT.size()));
       for (int64_t l = h; l < e->ncl; l += 2)
-        std::memcpy(T + global_of(e, l) * ld, &hT[(size_t)(l >> 1) * sh.lda], sizeof(double) * sh.m);
+        std::memcpy(T + global_of(e, l) * ld, &hT[(size_t)(l >> 1) * e->T.lda], sizeof(double) * sh.m);
     }
   }
   if (obj) {

@@ -1193,18 +1193,23 @@ __device__ __forceinline__ int64_t deep_run_index(int k, int s, int depth, int c
 // the row' values of every listed column side by side (rsl_*[k * stride + s] = row'_s of the k-th
 // listed column, zero beyond the chain), which the pass reads as one short run per column.  batch > 0: list_full's
 // runs in the layout of deep_run_index instead, and the address of every column of list_full in ptr_full.
+// bump_iter: the pivot count still lacks steps 1.. of this pass (k_chain_fused) and is advanced here.
 constexpr int kListThreads = 1024;   // one reservation in the lists per workgroup: the counters are single words every workgroup adds to
 __global__ __launch_bounds__(kListThreads) void k_chain_list(
     const double* __restrict__ rowp, int64_t rstride, int depth, const ChainStep* __restrict__ steps,
     const PivotState* __restrict__ st, int ncl, PassInfo* __restrict__ pass,
     int32_t* __restrict__ list_full, int32_t* __restrict__ list_part, double* __restrict__ rsl_full, double* __restrict__ rsl_part, int stride,
-    int batch, Tab T, uint64_t* __restrict__ ptr_full) {
+    int batch, Tab T, uint64_t* __restrict__ ptr_full, int bump_iter) {
   constexpr int kWaves = kListThreads / kWave;
   __shared__ int s_nf[kWaves], s_np[kWaves], s_tot[kWaves];
   __shared__ int s_bf, s_bp;
   if (st->status != ST_RUNNING) return;
   const int n_steps = chain_steps_done(steps, depth);
-  if (blockIdx.x == 0 && threadIdx.x == 0) pass->n_steps = n_steps;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    pass->n_steps = n_steps;
+    // steps 1.. were set up by k_chain_fused, which leaves the pivot count alone (its workgroups read it on entry)
+    if (bump_iter) const_cast<PivotState*>(st)->iter = st->iter + (n_steps - 1);
+  }
   const int l = blockIdx.x * blockDim.x + threadIdx.x;
   int nz = 0;
   if (l < ncl) {

@@ -214,3 +214,42 @@ def test_deep_pass_with_col_in_lds(lpamd, monkeypatch, depth, batch, chain, nt, 
     assert eng.trace() == dt.trace()
     assert_same_tableau(eng, dt)
     eng.close()
+
+
+@pytest.mark.parametrize("chain", [3, 24, 32])
+@pytest.mark.parametrize("knobs", [
+    {"LPAMD_FUSED": "0"},                                                           # step-by-step set-up kernels
+    {"LPAMD_FUSED": "1"},                                                           # default shape: one row / column per thread
+    {"LPAMD_FUSED": "1", "LPAMD_FUSED_THREADS": "512"},
+    {"LPAMD_FUSED": "1", "LPAMD_FUSED_THREADS": "1024"},                            # history from memory
+    {"LPAMD_FUSED": "1", "LPAMD_FUSED_REG": "0"},
+    {"LPAMD_FUSED": "1", "LPAMD_FUSED_ROWS": "2", "LPAMD_FUSED_COLS": "3"},         # several rows / columns per thread
+    {"LPAMD_FUSED": "1", "LPAMD_FUSED_ROWS": "1", "LPAMD_FUSED_COLS": "1"},
+], ids=lambda k: "-".join("%s%s" % (a.replace("LPAMD_FUSED", "F").replace("_", ""), b) for a, b in k.items()))
+def test_fused_setup_of_a_chain(lpamd, monkeypatch, depth, chain, knobs):
+    """k_chain_fused (steps 1.. of a chain set up by one launch of resident workgroups that hand results to each other
+    through tagged records) in every shape against the oracle: full solve, so chains that end at the optimum, and budgets
+    that end inside a chain."""
+    if depth != 2:
+        pytest.skip("one run is enough")
+    monkeypatch.setenv("LPAMD_CHAIN", str(chain))
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    m, n, seed = 2000, 900, 11
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    eng = lpamd.TableauEngine(m, n + m)
+    eng.fill_synthetic(n, seed)
+    total = 0
+    for k in (1, 2, chain - 1, chain, chain + 1, 5):
+        assert eng.run_pivots(lpamd.MAX_COST, k) == (lpamd.LIMIT, k)
+        total += k
+        assert dt.solve(lo.MAX_COST, max_pivots=total) == lo.LIMIT
+        assert eng.pivot_count() == total
+        assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    want = dt.solve(lo.MAX_COST)
+    res, npiv = eng.solve(lpamd.MAX_COST)
+    assert res == want == lpamd.SOLVED and npiv == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
