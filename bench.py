@@ -13,9 +13,11 @@ pivots per pass over the shard), one process per GPU: either the driver starts t
 torch.distributed.run, or a plain `python bench.py --gpus N` starts them itself (as a child
 torch.distributed.run, before this process touches a GPU).  Rank 0 prints ONE JSON line.
 
-The MAX_COST loop applies a chain of pivots per pass over the tableau, so the warm-up and the
-timed region are rounded UP to whole passes; the line reports the pivots actually timed
-("steps") next to the request ("steps_requested").
+The loops apply a chain of pivots per pass over the tableau, so the warm-up and the timed region
+are rounded UP to whole passes, and the timed region to at least three passes (the roofline figure
+is an average over the launches of the pass kernel); the line reports the pivots actually timed
+("steps") next to the request ("steps_requested").  A rank that cannot join the communicator of an
+N-GPU run within four minutes prints a JSON line with an "error" key and exits non-zero.
 """
 import argparse
 import importlib
@@ -46,6 +48,10 @@ CONFIGS = {
 }
 DEFAULT_CONFIG = "synthetic_m32768_n65536"
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+RMW_CEILING_GBS = 6360.0   # measured: a bare read-modify-write stream over two HBM placement classes (scripts/placement_microbench.hip)
+INFINITY_CACHE_BYTES = 256 << 20
+MIN_TIMED_PASSES = 3     # the roofline figure is an average over at least this many launches of the pass kernel
+JOIN_TIMEOUT_S = 240     # creating the communicator of an N-GPU run may not hang the benchmark
 FP64_VECTOR_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12   # one fp64 add or multiply per lane and clock, 16 lanes per SIMD
 
 
@@ -179,7 +185,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def fail(message):
+        """One JSON line that says what went wrong (stdout of rank 0, stderr of the others), then a hard exit."""
+        line = json.dumps({"metric": "simplex_pivots_per_sec", "value": None, "unit": "pivots/s", "n_gpus": world, "rank": rank,
+                           "error": message}) + "\n"
+        os.write(real_stdout if rank == 0 else 2, line.encode())
+        os._exit(3)
+
     group = None
+    rccl_ranks = 0
     if world == 1 and not force_sharded and not use_dist:
         eng = lp.TableauEngine(m, N)
         eng.fill_synthetic(n, args.seed)
@@ -188,13 +202,26 @@ def main():
         exchange = "none (device-resident loop)"
     else:
         if use_dist:
+            import threading
             ids = [lp.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            group = lp.ShardGroup.join(m, N, rank, world, ids[0])
+            watchdog = threading.Timer(JOIN_TIMEOUT_S, fail, ["rank %d did not get through ncclCommInitRank within %d s (another rank "
+                                                              "may have failed before it, or RCCL cannot reach its peers)" % (rank, JOIN_TIMEOUT_S)])
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                group = lp.ShardGroup.join(m, N, rank, world, ids[0])
+            except Exception as ex:
+                fail("rank %d could not create its shard or join the communicator: %s" % (rank, ex))
+            watchdog.cancel()
+            rccl_ranks = group.comm_ranks()
+            if rccl_ranks != world:
+                fail("the communicator holds %d ranks, WORLD_SIZE is %d" % (rccl_ranks, world))
         elif shard_of > 1:
             group = lp.ShardGroup(m, N, shard_of, devices=[local_rank] * shard_of, rehearse_rank0=True)
         else:
             group = lp.ShardGroup(m, N, 1, devices=[local_rank])
+        rccl_ranks = group.comm_ranks()
         group.fill_synthetic(n, args.seed)
         eng = group.engine(0)
         run = lambda k: group.run_pivots(strat, k)
@@ -203,7 +230,7 @@ def main():
 
     K, W = args.steps, args.warmup
     if not args.exact_steps:
-        K, W = round_up(max(K, 1), depth), round_up(W, depth)
+        K, W = max(round_up(max(K, 1), depth), MIN_TIMED_PASSES * depth), round_up(W, depth)
     res, done = run(W)
     assert done == W and res == lp.LIMIT, "warm-up ended early: result %d after %d pivots" % (res, done)
     sync_all()
@@ -229,10 +256,14 @@ def main():
     algo_bytes = 16.0 * m * touched_cols
     secs = max(upd_ms, 1e-9) * 1e-3
     achieved = streamed_bytes / secs / 1e9 if passes else 0.0
+    per_rank = None
     if use_dist:
-        t = torch.tensor([achieved], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)   # report the slowest rank's kernel rate
-        achieved = float(t.item())
+        mine = torch.tensor([achieved, upd_ms / max(passes, 1), float(streamed_cols) / max(passes, 1)], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [{"rank": k, "achieved_GBps": round(float(v[0]), 1), "frac": round(float(v[0]) / HBM_PEAK_GBS, 4),
+                     "avg_launch_ms": round(float(v[1]), 5), "streamed_columns_per_launch": round(float(v[2]), 1)} for k, v in enumerate(every)]
+        achieved = min(float(v[0]) for v in every)   # the line's figure is the slowest rank's kernel rate
     chained = passes > 0 and pivots > passes
     ratio, ratio_src = pmc_traffic_ratio(args.config, world, chained, args.strategy)
     per_launch = streamed_bytes / max(passes, 1)
@@ -254,7 +285,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.config, "m": m, "n": n, "stored_columns": N + 1, "strategy": args.strategy,
                    "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world,
-                   "exchange": exchange, "pivots_per_pass": depth,
+                   "exchange": exchange, "pivots_per_pass": depth, "rccl_ranks": rccl_ranks,
                    **({"rehearsal": "rank 0 of a %d-GPU run alone on one GPU" % shard_of} if shard_of > 1 else {})},
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),
@@ -264,6 +295,12 @@ def main():
                                       "note": "since the engine was created (warm-up included)"}} if priced else {}),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "frac_of_measured_rmw_ceiling": round(achieved / RMW_CEILING_GBS, 4),
+                     "applicable_roof": ("hbm" if 8.0 * m * (N + 2) / world > 2 * INFINITY_CACHE_BYTES else
+                                         "infinity cache (the shard of %.0f MB fits or nearly fits the 256 MiB memory-side cache: the HBM peak is "
+                                         "not what bounds this stream, and at this size the set-up of the pivots takes more of a pass than "
+                                         "the stream does)" % (8.0 * m * (N + 2) / world / 1e6)),
+                     **({"per_rank": per_rank} if per_rank else {}),
                      "traffic": round(ratio * per_launch) if ratio else None,
                      "traffic_source": ratio_src,
                      "kernel": ("k_update_deep" if pivots > 16 * passes else "k_update_slab") if chained else "k_update",

@@ -271,6 +271,9 @@ int lpamd_group_destroy(lpamd_group* g);
 /* shards held by this process / shards of the LP; the engine of a local shard (owned by the group:
  * for traces, statistics and read-back through the lpamd_* calls, not for pivoting) */
 int lpamd_group_shards(const lpamd_group* g, int32_t* n_local, int32_t* world);
+/* ranks the RCCL communicator of the first local shard really holds (ncclCommCount; 0 with the in-process exchange):
+ * what a multi-GPU run reports so that a mis-formed communicator is seen, not inferred */
+int lpamd_group_comm_ranks(lpamd_group* g, int32_t* ranks);
 int lpamd_group_engine(lpamd_group* g, int32_t local_index, lpamd_engine** out);
 /* pivots one pass over a shard sets up at most in the MAX_COST loop (LPAMD_SHARD_CHAIN overrides) */
 int lpamd_group_chain(lpamd_group* g, int32_t* pivots_per_pass);

@@ -298,6 +298,79 @@ int allocate_tableau(lpamd_engine* e) {
   return LPAMD_OK;
 }
 
+int push_state(lpamd_engine* e);
+int enqueue_chain_update(lpamd_engine* e);
+
+// The chain depth of an HBM-sized shard on one GPU, chosen by measurement.  Up to about 20 steps a pass costs the HBM time
+// of one stream over the shard; beyond, the fp64 vector rate (two separately rounded operations per entry and step) adds
+// 0.1 .. 0.2 ms per step, and where that sets in differs by a step or two from one machine to the next (shader clock under
+// load, HBM placement).  More steps per pass mean more pivots per second, so the deepest chain is taken whose pass still
+// streams at kProbeTarget of the 8 TB/s peak: k_chain_list and the pass kernel are timed at every candidate depth on the
+// freshly allocated shard (contents do not matter before the upload), with as many columns in the list as a pass
+// streams and steps that touch every column.  Three passes per candidate, from the deepest down.
+constexpr int kProbeMaxDepth = 24, kProbeMinDepth = 17;
+constexpr double kProbeTarget = 0.73, kProbePeakBytesPerMs = 8.0e9;
+int probe_chain_depth(lpamd_engine* e) {
+  const int32_t ncl_all = e->ncl;
+  const int64_t col_bytes = (int64_t)sizeof(double) * e->sh.lda;
+  // as many columns as a pass streams: the non-basic ones and the right-hand side (m of the N variables are basic, and
+  // their unit columns are skipped), from the front of the shard like the dense columns of a fresh tableau
+  const int64_t dense = std::max<int64_t>(64, e->sh.N - e->sh.m + 2);
+  e->ncl = (int32_t)std::min<int64_t>(ncl_all, std::min<int64_t>(dense, ((int64_t)64 << 30) / col_bytes));
+  const bool verbose = getenv("LPAMD_DEPTH_PROBE_VERBOSE") != nullptr;
+  // Random entries, as a dense LP has them (the synthetic generator; every probed column is a structural one): a shard of
+  // equal numbers streams 7 % faster than one of random numbers at 24 steps per pass (5.77 against 6.16 ms at m=32768
+  // n=65536), presumably the vector units' power.  col'_s: copies of a column; row'_s: 0.001 everywhere, so that nothing
+  // grows or comes near the small-magnitude threshold over the few hundred steps of the probe.
+  hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)e->ncl, (unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->obj,
+                     e->is_basic, e->basis, e->sh, (int64_t)e->ncl, (uint64_t)12345);
+  LP_TRY(check_launch("k_fill_synthetic"));
+  for (int s = 0; s < kProbeMaxDepth; s++)
+    HIP_TRY(hipMemcpyAsync(e->colp + (int64_t)s * e->sh.lda, e->T.col(s % e->ncl), sizeof(double) * e->sh.lda, hipMemcpyDeviceToDevice, e->stream));
+  hipLaunchKernelGGL(k_fill, dim3((unsigned)((e->rstride * kProbeMaxDepth + 255) / 256)), dim3(256), 0, e->stream, e->rowp, e->rstride * kProbeMaxDepth, 1e-3);
+  LP_TRY(check_launch("k_fill"));
+  int chosen = 16;
+  double chosen_frac = 0.0;
+  std::vector<ChainStep> hsteps(kMaxChain);
+  for (int d = kProbeMaxDepth; d >= kProbeMinDepth; d--) {
+    e->chain_depth = d;
+    std::memset(hsteps.data(), 0, sizeof(ChainStep) * kMaxChain);
+    for (int s = 1; s < d; s++) hsteps[s].done = 1;
+    HIP_TRY(hipMemcpyAsync(e->steps, hsteps.data(), sizeof(ChainStep) * kMaxChain, hipMemcpyHostToDevice, e->stream));
+    std::memset(&e->h_st, 0, sizeof(PivotState));   // status RUNNING
+    LP_TRY(push_state(e));
+    double ms = 0.0;
+    for (int rep = 0; rep < 3; rep++) {
+      HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
+      e->profiling = rep > 0;                        // the first pass warms up
+      LP_TRY(enqueue_chain_update(e));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    for (size_t k = 0; k + 1 < e->ev_used; k += 2) {
+      float t = 0.f;
+      HIP_TRY(hipEventElapsedTime(&t, e->ev[k], e->ev[k + 1]));   // k_chain_list + the pass, as the benchmark times them
+      ms += t;
+    }
+    ms /= std::max<size_t>(1, e->ev_used / 2);
+    e->ev_used = 0;
+    e->profiling = false;
+    const double frac = 2.0 * col_bytes * e->ncl / std::max(ms, 1e-6) / kProbePeakBytesPerMs;
+    if (verbose) fprintf(stderr, "lpamd depth probe: %d steps per pass, %.3f ms over %d columns, %.4f of the HBM peak\n", d, ms, e->ncl, frac);
+    if (frac >= kProbeTarget && chosen_frac == 0.0) { chosen = d; chosen_frac = frac; if (!verbose) break; }
+  }
+  if (verbose) fprintf(stderr, "lpamd depth probe: chose %d (%.4f)\n", chosen, chosen_frac);
+  e->chain_depth = chosen;
+  e->deep_batch = chosen > 16 ? e->deep_batch : 0;
+  e->ncl = ncl_all;
+  HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
+  HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
+  HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * kProbeMaxDepth, e->stream));   // rows beyond m must read zero
+  HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda * kProbeMaxDepth, e->stream));
+  std::memset(&e->h_st, 0, sizeof(PivotState));
+  LP_TRY(push_state(e));
+  return LPAMD_OK;
+}
+
 int pull_state(lpamd_engine* e) {
   e->apply_since_pull = 0;
   HIP_TRY(hipMemcpyAsync(&e->h_st, e->st, sizeof(PivotState), hipMemcpyDeviceToHost, e->stream));
@@ -883,10 +956,16 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // every machine seen.  Shards that fit the Infinity Cache are bound by the set-up launches and stay at 16.
   const bool hbm_sized = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
   e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 22 : 16);
+  // One GPU, HBM-sized shard: the depth is MEASURED on this device once everything is allocated (probe_chain_depth), from
+  // kProbeMaxDepth down; the buffers are sized for that.  Column shards keep 22: every rank must chain the same number of steps.
+  bool probe_depth = world == 1 && hbm_sized && !e->two_launch;
+  if (const char* env = getenv("LPAMD_DEPTH_PROBE")) probe_depth = probe_depth && atoi(env) != 0;
   if (const char* env = getenv("LPAMD_CHAIN")) {
     e->chain_depth = std::max(1, std::min(kMaxChain, atoi(env)));
     if (e->chain_depth > 1) e->two_launch = false;
+    probe_depth = false;
   }
+  if (probe_depth) e->chain_depth = kProbeMaxDepth;
   // Measured (m=32768 n=65536): col' from L2 8.44 ms per pass of 8 pivots; in registers, 1024-row slabs x 8 columns in
   // flight 5.65 ms per pass of 16 pivots (the HBM time of one pass), x 4 columns 5.91 ms, 512-row slabs x 8 columns 6.64 ms
   // shards inside the Infinity Cache (m=4096 n=8192: 0.134 -> 0.116 ms per pass of 16 pivots) take the 512-row slabs as well: twice the workgroups
@@ -1022,6 +1101,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   std::memset(&e->h_st, 0, sizeof(PivotState));
   LP_TRY(ensure_trace(e, 4096));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  if (probe_depth && e->deep_batch > 0) LP_TRY(probe_chain_depth(e));
   return LPAMD_OK;
 }
 

@@ -121,6 +121,8 @@ struct RcclApi {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommInitAll) CommInitAll = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclCommAbort) CommAbort = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
@@ -145,6 +147,8 @@ int rccl_api(RcclApi** out) {
     LPAMD_RCCL_SYM(CommInitRank, "ncclCommInitRank");
     LPAMD_RCCL_SYM(CommInitAll, "ncclCommInitAll");
     LPAMD_RCCL_SYM(CommDestroy, "ncclCommDestroy");
+    LPAMD_RCCL_SYM(CommAbort, "ncclCommAbort");
+    LPAMD_RCCL_SYM(CommCount, "ncclCommCount");
     LPAMD_RCCL_SYM(AllGather, "ncclAllGather");
     LPAMD_RCCL_SYM(GetErrorString, "ncclGetErrorString");
 #undef LPAMD_RCCL_SYM
@@ -201,6 +205,7 @@ struct lpamd_shard {   // one column shard of a group and its exchange state
   hipEvent_t ev_sent = nullptr, ev_arrived = nullptr;
   hipEvent_t ev_pub = nullptr, ev_read = nullptr;   // in-process exchange
   ncclComm_t comm = nullptr;
+  bool comm_aborted = false;                 // a shard of this process failed: the communicator was torn down with ncclCommAbort
   uint64_t* slot = nullptr;                  // slot_words words (record, column, ratio-test partials): what this rank sends
   uint64_t* slots = nullptr;                 // world slots: what every rank receives
   double* xbuf = nullptr;                    // lda doubles: the entering column of the pivot being set up
@@ -223,12 +228,18 @@ struct lpamd_group {
   std::vector<lpamd_shard> shards;           // the shards this process holds
   std::vector<const void*> pub;              // in-process exchange: what every rank offers
   HostBarrier barrier;
+  std::mutex abort_mu;
 };
 
 namespace {
 
 using Group = lpamd_group;
 using Shard = lpamd_shard;
+
+// A shard of this process has failed: the collectives the others have enqueued would wait for it for ever (and with
+// them every hipStreamSynchronize behind them), so every communicator this process holds is aborted.  The group is
+// unusable afterwards; lpamd_group_destroy skips the aborted communicators.
+void abort_comms(lpamd_group* g);
 
 // Runs fn on every local shard, one host thread per shard when there are several (the loops
 // are collective: all shards must be inside them at the same time).  The first failure wins.
@@ -237,7 +248,14 @@ int for_each_shard(Group* g, Fn fn) {
   if (g->shards.size() == 1) {
     Shard& s = g->shards[0];
     HIP_TRY(hipSetDevice(s.device));
-    return fn(s);
+    const int rc = fn(s);
+    if (rc != LPAMD_OK) {   // one process per GPU: the peers' collectives would wait for this rank for ever
+      char keep[sizeof(g_err)];
+      std::memcpy(keep, g_err, sizeof(keep));
+      abort_comms(g);
+      std::memcpy(g_err, keep, sizeof(keep));
+    }
+    return rc;
   }
   g->barrier.reset((int)g->shards.size());
   std::vector<std::thread> threads;
@@ -250,6 +268,7 @@ int for_each_shard(Group* g, Fn fn) {
       if (s.rc != LPAMD_OK) {
         s.err = g_err;            // g_err is per thread
         g->barrier.abort();       // nobody waits for a shard that gave up
+        abort_comms(g);           // ... nor inside a collective whose peer will never arrive
       }
     });
   }
@@ -259,11 +278,25 @@ int for_each_shard(Group* g, Fn fn) {
   return LPAMD_OK;
 }
 
+void abort_comms(Group* g) {
+  if (g->local_exchange) return;
+  RcclApi* api = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!g_rccl.so) return;
+    api = &g_rccl;
+  }
+  std::lock_guard<std::mutex> lock(g->abort_mu);
+  for (Shard& q : g->shards)
+    if (q.comm && !q.comm_aborted) { q.comm_aborted = true; (void)api->CommAbort(q.comm); }
+}
+
 // All-gather of `words` 64-bit words per rank on `stream` (send and recv are device memory).
 int all_gather_words(Group* g, Shard& s, const uint64_t* send, uint64_t* recv, int64_t words, hipStream_t stream) {
   if (!g->local_exchange) {
     RcclApi* api = nullptr;
     LP_TRY(rccl_api(&api));
+    if (s.comm_aborted) return set_err(LPAMD_E_STATE, "another shard failed");
     RCCL_TRY(api, api->AllGather(send, recv, (size_t)words, ncclUint64, s.comm, stream));
     return LPAMD_OK;
   }
@@ -611,9 +644,9 @@ int solve_shard(Group* g, Shard& s, int32_t strategy, int64_t max_pivots, int32_
 
 void destroy_shard(Group* g, Shard& s) {
   (void)hipSetDevice(s.device);
-  if (s.eng && s.eng->stream) (void)hipStreamSynchronize(s.eng->stream);
+  if (s.eng && s.eng->stream) (void)hipStreamSynchronize(s.eng->stream);   // (returns once an aborted collective has been flushed)
   if (s.xstream) (void)hipStreamSynchronize(s.xstream);
-  if (s.comm) {
+  if (s.comm && !s.comm_aborted) {   // ncclCommAbort has already released an aborted communicator
     RcclApi* api = nullptr;
     if (rccl_api(&api) == LPAMD_OK) (void)api->CommDestroy(s.comm);
   }
@@ -664,8 +697,11 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   // one GPU and 64 pivots between two reads of the pivot state, that backlog was seen to exhaust something in the
   // driver that every process on the machine needs (other processes' HSA start-up crashed until the backlog had
   // drained); 16 pivots between reads keep it short.  RCCL exchanges enqueue one collective per pivot and keep 64.
+  // Every cross-stream event wait is a barrier packet with a completion signal of its own in the queue, so the likely
+  // resource is the runtime's pool of signals / the queue's packet ring.  The bound holds whatever the environment asks for.
   if (g->local_exchange) g->poll_every = 16;
   if (const char* env = getenv("LPAMD_SHARD_POLL")) g->poll_every = std::max(1, atoi(env));
+  g->poll_every = std::min(g->poll_every, g->local_exchange ? 16 : 64);
   if (const char* env = getenv("LPAMD_SHARD_FUSED")) g->fused_step = atoi(env) != 0;
   return g;
 }
@@ -750,7 +786,8 @@ int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards
 int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id) {
   if (!out) return set_err(LPAMD_E_ARG, "group_create_rank: out is null");
   *out = nullptr;
-  if (m <= 0 || N <= 0 || world <= 0 || rank < 0 || rank >= world || !comm_id)
+  // (world > N + 1 would leave a rank without a column: every rank must see that BEFORE any of them enters ncclCommInitRank)
+  if (m <= 0 || N <= 0 || world <= 0 || world > N + 1 || rank < 0 || rank >= world || !comm_id)
     return set_err(LPAMD_E_ARG, "group_create_rank: bad arguments m=%lld N=%lld rank=%d world=%d", (long long)m, (long long)N, rank, world);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
@@ -765,6 +802,9 @@ int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t ran
       std::memcpy(&id, comm_id, sizeof(id));
       ncclResult_t r = api->CommInitRank(&g->shards[0].comm, world, id, rank);
       if (r != ncclSuccess) rc = set_err(LPAMD_E_HIP, "ncclCommInitRank failed: %s", api->GetErrorString(r));
+      int count = 0;
+      if (rc == LPAMD_OK && (api->CommCount(g->shards[0].comm, &count) != ncclSuccess || count != world))
+        rc = set_err(LPAMD_E_STATE, "the communicator holds %d ranks, %d expected", count, world);
     }
   }
   if (rc == LPAMD_OK) rc = finish_group(g);
@@ -793,6 +833,19 @@ int lpamd_group_shards(const lpamd_group* g, int32_t* n_local, int32_t* world) {
   CHECK_GROUP(g);
   if (n_local) *n_local = (int32_t)g->shards.size();
   if (world) *world = g->world;
+  return LPAMD_OK;
+}
+
+int lpamd_group_comm_ranks(lpamd_group* g, int32_t* ranks) {
+  CHECK_GROUP(g);
+  if (!ranks) return set_err(LPAMD_E_ARG, "group_comm_ranks: null");
+  *ranks = 0;
+  if (g->local_exchange || !g->shards[0].comm || g->shards[0].comm_aborted) return LPAMD_OK;
+  RcclApi* api = nullptr;
+  LP_TRY(rccl_api(&api));
+  int count = 0;
+  RCCL_TRY(api, api->CommCount(g->shards[0].comm, &count));
+  *ranks = count;
   return LPAMD_OK;
 }
 

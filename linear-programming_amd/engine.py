@@ -96,6 +96,7 @@ def library():
         "lpamd_group_create_rank": (ctypes.c_int, [P(vp), i64, i64, i32, i32, vp]),
         "lpamd_group_destroy": (ctypes.c_int, [vp]),
         "lpamd_group_shards": (ctypes.c_int, [vp, P(i32), P(i32)]),
+        "lpamd_group_comm_ranks": (ctypes.c_int, [vp, P(i32)]),
         "lpamd_group_engine": (ctypes.c_int, [vp, i32, P(vp)]),
         "lpamd_group_chain": (ctypes.c_int, [vp, P(i32)]),
         "lpamd_group_upload": (ctypes.c_int, [vp, vp, i64, vp, vp]),
@@ -158,21 +159,29 @@ def ratio_test_noalloc(col_ptr, rhs_ptr, m, row_out_ptr, ratio_out_ptr=None, str
 class TableauEngine:
     """Device-resident m x (N+2) tableau shard on the current HIP device."""
 
-    def __init__(self, m, N, rank=0, world=1, stream=None, borrowed=None):
+    def __init__(self, m, N, rank=0, world=1, stream=None, borrowed=None, group=None):
         self.L = library()
         self.m, self.N, self.rank, self.world = int(m), int(N), int(rank), int(world)
         self.owned = borrowed is None
+        self.group = group                # a view keeps its group alive and goes dead with it (ShardGroup.close)
         if borrowed is not None:          # a shard of a ShardGroup: the group owns the handle
-            self.h = ctypes.c_void_p(borrowed)
+            self._h = ctypes.c_void_p(borrowed)
             return
-        self.h = ctypes.c_void_p()
-        _ck(self.L.lpamd_create(ctypes.byref(self.h), self.m, self.N, self.rank, self.world,
+        self._h = ctypes.c_void_p()
+        _ck(self.L.lpamd_create(ctypes.byref(self._h), self.m, self.N, self.rank, self.world,
                                 ctypes.c_void_p(stream) if stream else None))
 
+    @property
+    def h(self):
+        """The engine handle; a view of a shard refuses once its group has been closed (the handle is freed memory then)."""
+        if not self.owned and (self.group is None or not self.group.h):
+            raise LpamdError("this engine is a view of a ShardGroup that has been closed")
+        return self._h
+
     def close(self):
-        if self.h and self.owned:
-            self.L.lpamd_destroy(self.h)
-        self.h = ctypes.c_void_p()
+        if self._h and self.owned:
+            self.L.lpamd_destroy(self._h)
+        self._h = ctypes.c_void_p()
 
     def __del__(self):
         try:
@@ -446,9 +455,15 @@ class ShardGroup:
         """Local shard k as a TableauEngine view (trace, statistics, read-back; the group keeps ownership)."""
         h = ctypes.c_void_p()
         _ck(self.L.lpamd_group_engine(self.h, int(k), ctypes.byref(h)))
-        e = TableauEngine(self.m, self.N, borrowed=h.value)
+        e = TableauEngine(self.m, self.N, borrowed=h.value, group=self)
         e.world = self.world
         return e
+
+    def comm_ranks(self):
+        """Ranks of the RCCL communicator (0: in-process exchange)."""
+        n = ctypes.c_int32()
+        _ck(self.L.lpamd_group_comm_ranks(self.h, ctypes.byref(n)))
+        return n.value
 
     def chain(self):
         d = ctypes.c_int32()
