@@ -21,6 +21,7 @@ constexpr int kRadix = 92;           // digits of a general number; also the val
 constexpr int kHalf = 46;            // digits of an index; a digit >= 46 closes a multi-digit index
 constexpr int kQuarter = 23;
 constexpr size_t kLinesPerCheck = 71;
+constexpr long kFieldLimit = 1L << 52;   // no index or integer of a real file comes near; 46 times this still fits a long
 const char* const kBoundKinds[] = {"UP", "LO", "FX", "FR", "MI", "PL"};
 
 std::string Clip(const std::string& s, size_t width) { return s.substr(0, std::min(width, s.find('\0') == std::string::npos ? s.size() : s.find('\0'))); }
@@ -50,7 +51,7 @@ class Expander {
       const bool ok1 = std::sscanf(line_.c_str(), "%ld %ld %ld %ld %ld %ld %ld %ld", &nrow_, &ncol, &colmax, &nz, &nrhs, &rhsnz, &nran, &ranz) == 8;
       if (ok1) NextLine();
       if (!ok1 || std::sscanf(line_.c_str(), "%ld %ld %ld", &nbd, &bdnz, &ns) != 3) Fail("bad statistics line: " + line_);
-      if (nrow_ < 0 || ncol < 0 || ns < 0 || nrow_ + ncol > (1L << 30)) Fail("problem too big");
+      if (nrow_ < 0 || ncol < 0 || ns < 0 || ns > (1L << 26) || nrow_ + ncol > (1L << 26)) Fail("problem too big");
       check_.clear();   // the NAME and statistics lines are outside the checksums
       names_.assign(size_t(nrow_ + ncol) + 1, std::string());
       next_name_ = nrow_;
@@ -158,6 +159,7 @@ class Expander {
     long x = k;
     for (;;) {
       k = Take();
+      if (x > kFieldLimit) Fail("index field too long");   // a crafted line must not overflow the accumulator
       x = x * kHalf + k;
       if (k >= kHalf) return x - kHalf;
     }
@@ -187,6 +189,7 @@ class Expander {
         x = k;
         for (;;) {
           k = Take();
+          if (x > kFieldLimit) Fail("integer field too long");
           x = x * kHalf + k;
           if (k >= kHalf) { x -= kHalf; break; }
         }
@@ -272,7 +275,7 @@ class Expander {
         NextLine();
       }
       if (kind >= 4) {
-        if (n >= 7) Fail("bad bound type index = " + std::to_string(n));
+        if (n < 1 || n >= 7) Fail("bad bound type index = " + std::to_string(n));
         Refill();
         name[0] = FetchName(nrow_ + Index());
         if (n-- >= 4) {   // FR, MI, PL carry no value

@@ -144,6 +144,11 @@ struct lpamd_engine {
   // host mirrors
   PivotState h_st{};
   bool loaded = false;
+  // Basic columns are no longer unit columns (PivotState::dirty): pivots are chosen by the loop that scans like the reference
+  bool dirty_basis = false;
+  unsigned long long* first_basic = nullptr;   // [m] k_basic_scan_rows
+  long long* basis_disc = nullptr;             // [m] k_basis_discovery
+  bool dense_first = false;   // host view of PivotState::dense_next: the next pivot must be a single one that reaches every column
   // profiling of the update kernel
   bool profiling = false;
   std::vector<hipEvent_t> ev;
@@ -187,6 +192,7 @@ int ensure_trace(lpamd_engine* e, int64_t need) {
 }
 
 int check_launch(const char* what);
+int run_loop_device(lpamd_engine* e, int strategy, int64_t budget, int32_t* result);
 
 // ---- tableau allocation with HBM placement ------------------------------------
 // Measured on MI355X (scripts/placement_microbench.hip, profiles/): the address space of
@@ -375,6 +381,7 @@ int pull_state(lpamd_engine* e) {
   e->apply_since_pull = 0;
   HIP_TRY(hipMemcpyAsync(&e->h_st, e->st, sizeof(PivotState), hipMemcpyDeviceToHost, e->stream));
   HIP_TRY(hipStreamSynchronize(e->stream));
+  e->dense_first = e->h_st.dense_next != 0;
   return LPAMD_OK;
 }
 int push_state(lpamd_engine* e) {
@@ -480,15 +487,16 @@ int enqueue_update(lpamd_engine* e, bool fuse_pr) {
   return LPAMD_OK;
 }
 
-int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, const double* xcol) {
+int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, const double* xcol, const unsigned long long* first_basic = nullptr);
+int enqueue_ratio_partial(lpamd_engine* e, bool fold_price, Candidate* cand, const double* xcol, const unsigned long long* first_basic) {
   double* rv = e->part_v + kMaxPartials;
   int64_t* ri = e->part_i + kMaxPartials;
   if (fold_price)
     hipLaunchKernelGGL(k_ratio_partial<true>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->part_v,
-                       e->part_i, e->n_price_part, cand, xcol, rv, ri);
+                       e->part_i, e->n_price_part, cand, xcol, rv, ri, first_basic);
   else
     hipLaunchKernelGGL(k_ratio_partial<false>, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->part_v,
-                       e->part_i, e->n_price_part, cand, xcol, rv, ri);
+                       e->part_i, e->n_price_part, cand, xcol, rv, ri, first_basic);
   return check_launch("k_ratio_partial");
 }
 
@@ -799,8 +807,93 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
   return enqueue_finalize_update(e, false, e->cand, nullptr, -1, strategy == LPAMD_MAX_REDUCTION);
 }
 
+int read_local(const lpamd_engine* e, const void* src, void* dst, size_t bytes);
+
+// The main loop for a tableau whose basic columns are no longer unit columns (PivotState::dirty; one GPU): one pivot per
+// pass, the leaving variable and the rows that take part found the reference's way on every iteration.  MAX_COST
+// (reference lp_simplex_tableau.cc:188-227): a row takes part in the ratio test only if some basic column has a non-zero
+// entry in it, and the first such column leaves.  MAX_REDUCTION (reference lp_simplex_tableau.cc:235-374): the basic
+// variable of a row comes from the discovery loop over the basic columns; a row without one makes the result UNBOUNDED.
+// The host reads the choice back once per pivot: this loop serves inputs on which the reference's arithmetic has already
+// lost its footing (entries of 4e9 and more), and what counts here is that the same pivots are taken.
+int run_loop_scanning(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
+  if (e->sh.world != 1) return set_err(LPAMD_E_UNSUPPORTED, "basic columns are no longer unit columns (entries of 4e9 and more); the loop that handles this needs the tableau on one GPU");
+  const Shape& sh = e->sh;
+  if (!e->first_basic) {
+    HIP_TRY(hipMalloc(&e->first_basic, sizeof(unsigned long long) * sh.m));
+    HIP_TRY(hipMalloc(&e->basis_disc, sizeof(long long) * sh.m));
+  }
+  LP_TRY(pull_state(e));
+  const int64_t stop_at = budget < 0 ? std::numeric_limits<int64_t>::max() : e->h_st.iter + budget;
+  e->h_st.status = ST_RUNNING;
+  e->h_st.max_iter = std::numeric_limits<int64_t>::max();
+  e->h_st.dirty = 2;   // known: the first kernels of an iteration go on
+  e->h_st.dirty_step = 0;
+  e->h_st.n_active = e->h_st.n_active2 = 0;
+  LP_TRY(push_state(e));
+  e->dirty_basis = true;
+  for (;;) {
+    if (e->h_st.iter >= stop_at) { *result = LPAMD_LIMIT; return LPAMD_OK; }
+    LP_TRY(ensure_trace(e, e->h_st.iter + 2));
+    Candidate c;
+    long long d = -1;
+    if (strategy == LPAMD_MAX_COST) {
+      HIP_TRY(hipMemsetAsync(e->first_basic, 0xFF, sizeof(unsigned long long) * sh.m, e->stream));
+      hipLaunchKernelGGL(k_basic_scan_rows, dim3(sh.nloc), dim3(256), 0, e->stream, e->T, sh, e->is_basic, e->first_basic);
+      LP_TRY(check_launch("k_basic_scan_rows"));
+      e->price_partials_fresh = false;
+      LP_TRY(enqueue_pricing(e, LPAMD_MAX_COST, e->cand));
+      LP_TRY(enqueue_ratio_partial(e, false, e->cand, nullptr, e->first_basic));
+      LP_TRY(read_local(e, e->cand, &c, sizeof(c)));
+      if (c.gcol < 0) { *result = LPAMD_SOLVED; return LPAMD_OK; }              // :201-205
+      std::vector<double> rv(e->n_ratio_part);
+      std::vector<int64_t> ri(e->n_ratio_part);
+      LP_TRY(read_local(e, e->part_v + kMaxPartials, rv.data(), sizeof(double) * rv.size()));
+      LP_TRY(read_local(e, e->part_i + kMaxPartials, ri.data(), sizeof(int64_t) * ri.size()));
+      double bv = 0.0;
+      int64_t bi = -1;
+      for (size_t k = 0; k < rv.size(); k++)   // smaller ratio, then lower row
+        if (ri[k] >= 0 && (bi < 0 || rv[k] < bv || (rv[k] == bv && ri[k] < bi))) { bv = rv[k]; bi = ri[k]; }
+      if (bi < 0) { *result = LPAMD_UNBOUNDED; return LPAMD_OK; }               // :230-233
+      unsigned long long fb = 0;
+      LP_TRY(read_local(e, e->first_basic + bi, &fb, sizeof(fb)));
+      c.row = bi;
+      d = (long long)fb;
+    } else {
+      HIP_TRY(hipMemsetAsync(e->basis_disc, 0xFF, sizeof(long long) * sh.m, e->stream));   // -1 everywhere
+      hipLaunchKernelGGL(k_basis_discovery, dim3(sh.nloc), dim3(256), 0, e->stream, e->T, sh, e->is_basic, e->basis_disc);
+      LP_TRY(check_launch("k_basis_discovery"));
+      LP_TRY(enqueue_pricing(e, LPAMD_MAX_REDUCTION, e->cand));
+      LP_TRY(read_local(e, e->cand, &c, sizeof(c)));
+      if (c.gcol < 0) { *result = LPAMD_SOLVED; return LPAMD_OK; }              // :365-369
+      if (c.row < 0) { *result = LPAMD_UNBOUNDED; return LPAMD_OK; }            // :370-373
+      LP_TRY(read_local(e, e->basis_disc + c.row, &d, sizeof(d)));
+      if (d < 0) { *result = LPAMD_UNBOUNDED; return LPAMD_OK; }                // no basic variable was discovered for the row: d stays undefined, :370
+    }
+    HIP_TRY(hipMemcpyAsync(e->cand, &c, sizeof(c), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));   // c is a stack object
+    LP_TRY(enqueue_finalize_update(e, false, e->cand, nullptr, (int64_t)d, strategy == LPAMD_MAX_REDUCTION));
+    LP_TRY(pull_state(e));
+    if (e->h_st.status != ST_RUNNING) { *result = status_to_result(e->h_st.status); return LPAMD_OK; }
+  }
+}
+
 // Device-resident main loop: at most `budget` pivots (budget < 0: none).
 int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
+  if (e->dirty_basis) return run_loop_scanning(e, strategy, budget, result);
+  {
+    int64_t before = 0;
+    LP_TRY(pull_state(e));
+    before = e->h_st.iter;
+    LP_TRY(run_loop_device(e, strategy, budget, result));
+    if (e->h_st.status != ST_DIRTY) return LPAMD_OK;
+    // the device loop met a column whose entries no longer cancel to a unit column: the rest of the run scans like the reference
+    const int64_t used = e->h_st.iter - before;
+    return run_loop_scanning(e, strategy, budget < 0 ? budget : std::max<int64_t>(0, budget - used), result);
+  }
+}
+
+int run_loop_device(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   LP_TRY(pull_state(e));
   if (budget == 0) { *result = LPAMD_LIMIT; return LPAMD_OK; }   // nothing to enqueue: the budget is spent before the first pivot
   e->h_st.status = ST_RUNNING;
@@ -820,6 +913,22 @@ int run_loop(lpamd_engine* e, int strategy, int64_t budget, int32_t* result) {
   } restore{e};
   // With a budget the whole run is enqueued at once (kernels turn into no-ops
   // once the status leaves RUNNING); without one the batch grows geometrically.
+  if (e->dense_first && !e->two_launch) {
+    // the first pivot after an upload with entries below the drop threshold: one pivot per pass, every column (the
+    // two-launch loop is one pivot per pass anyway)
+    if (strategy == LPAMD_MAX_COST) {
+      LP_TRY(enqueue_price_partial(e));
+      LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
+      LP_TRY(enqueue_finalize_update(e, true, e->cand, nullptr, -1));
+    } else {
+      LP_TRY(enqueue_pricing(e, strategy, e->cand));
+      LP_TRY(enqueue_finalize_update(e, false, e->cand, nullptr, -1, strategy == LPAMD_MAX_REDUCTION));
+    }
+    LP_TRY(pull_state(e));
+    e->price_partials_fresh = e->price_partials_fresh && strategy == LPAMD_MAX_COST;
+    if (e->h_st.status != ST_RUNNING) { *result = status_to_result(e->h_st.status); return LPAMD_OK; }
+    if (budget >= 0 && e->h_st.iter >= e->h_st.max_iter) { *result = LPAMD_LIMIT; return LPAMD_OK; }
+  }
   int64_t batch = budget >= 0 ? 1024 : 8;
   const int64_t depth = (strategy == LPAMD_MAX_COST || (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds)) ? e->chain_depth : 1;   // pivots an iteration may apply
   e->loop_depth = (int32_t)depth;
@@ -1111,7 +1220,7 @@ int lpamd_destroy(lpamd_engine* e) {
   if (e->stream) (void)hipStreamSynchronize(e->stream);
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
   void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->ptr_full,
-                  e->rec_ratio, e->rec_price, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
+                  e->rec_ratio, e->rec_price, e->first_basic, e->basis_disc, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1142,13 +1251,43 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
     for (int64_t i = 0; i < sh.m; i++)
       if (!h_is_zero(T[g * ld + i])) { basis[i] = g; break; }
   }
+  // Stored entries the zero drop would not have let through (0 < |x| < 1e-6; the reference keeps right-hand sides however
+  // small, reference lp.cc:180): the first pivot then reaches every column, see PivotState::dense_next.  Looked for in the
+  // WHOLE matrix, not only this rank's columns, so that all ranks of a group agree.
+  bool tiny = false;
+  for (int64_t g = 0; g < sh.N + 2 && !tiny; g++)
+    for (int64_t i = 0; i < sh.m; i++) {
+      const double x = T[g * ld + i];
+      if (x != 0.0 && std::fabs(x) < (double)1e-6f) { tiny = true; break; }
+    }
   for (int h = 0; h < 2; h++)
     if (!hT[h].empty())
       HIP_TRY(hipMemcpyAsync(e->T.half[h], hT[h].data(), sizeof(double) * hT[h].size(), hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->obj, hobj.data(), sizeof(double) * e->ncl, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->is_basic, hb.data(), e->ncl, hipMemcpyHostToDevice, e->stream));
   HIP_TRY(hipMemcpyAsync(e->basis, basis.data(), sizeof(int64_t) * sh.m, hipMemcpyHostToDevice, e->stream));
+  // The device loops rely on every basic column being a unit column, one per row (PivotState::dirty); a tableau that does
+  // not start that way is solved by the loop that scans like the reference from the first pivot on.
+  bool unit_basis = true;
+  {
+    std::vector<uint8_t> covered(sh.m, 0);
+    int64_t n_basic = 0;
+    for (int64_t g = 0; g < sh.N && unit_basis; g++) {
+      if (!is_basic[g]) continue;
+      n_basic++;
+      int64_t nz = 0, at = -1;
+      for (int64_t i = 0; i < sh.m; i++)
+        if (!h_is_zero(T[g * ld + i])) { nz++; at = i; }
+      if (nz != 1 || covered[at]) unit_basis = false;
+      else covered[at] = 1;
+    }
+    if (n_basic != sh.m) unit_basis = false;
+  }
   reset_state(e);
+  e->dirty_basis = false;
+  e->h_st.dirty = unit_basis ? 0 : 1;
+  e->h_st.dense_next = tiny ? 1 : 0;
+  e->dense_first = tiny;
   LP_TRY(invalidate_pr(e));
   LP_TRY(push_state(e));
   e->loaded = true;
@@ -1165,6 +1304,8 @@ int lpamd_fill_synthetic(lpamd_engine* e, int64_t n_struct, uint64_t seed) {
                      e->is_basic, e->basis, sh, n_struct, seed);
   LP_TRY(check_launch("k_fill_synthetic"));
   reset_state(e);
+  e->dense_first = false;
+  e->dirty_basis = false;
   LP_TRY(invalidate_pr(e));
   LP_TRY(push_state(e));
   e->loaded = true;
@@ -1775,6 +1916,7 @@ int lpamd_chain_step(lpamd_engine* e, void* xbuf_dev) {
   CHECK_LOADED(e);
   if (!xbuf_dev) return set_err(LPAMD_E_ARG, "chain_step: null exchange buffer");
   if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain_step: no pivot has been set up by lpamd_lookahead_setup");
+  if (e->dense_first) return set_err(LPAMD_E_STATE, "chain_step: the first pivot after this upload must be applied alone (entries below the drop threshold)");
   if (e->pending_steps >= e->chain_depth)
     return set_err(LPAMD_E_STATE, "chain_step: the pass already holds %d pivots", e->pending_steps);
   e->apply_since_pull++;

@@ -146,7 +146,8 @@ struct FusedFold {
   int64_t idx;     // winning column / row, -1 none
   int64_t d_old;   // ratio records: basis[] entry of the winning row
   int32_t l;       // ratio records: entering column
-  int32_t flags;   // 1: a poll gave up; 2: the chain ends before this step
+  int32_t flags;   // 1: a poll gave up; 2: the chain ends before this step; 4: the entering column of this step holds an
+                   // entry of kDirtyBound or more (PivotState::dirty): the step is set up, the chain ends behind it
 };
 
 // kReg: every thread owns at most ONE row (row workgroups) or column (column workgroups) and keeps what the steps so far
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
   int64_t q_e = -1, q_r = -1;      // step `lane` (lane 0: pivot 0): entering variable and pivot row
   if (lane == 0) { q_e = st->e; q_r = st->r; }
   if (status != ST_RUNNING) return;
+  if (st->dirty_step == 1) return;   // pivot 0 ends the chain (PivotState::dirty); this launch itself only ever writes 2 and more
   const bool keeper = cb == 0 && tid == 0;
   if (keeper) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
   // step j exists budget-wise while it0 + (j - 1) < max_iter
@@ -197,21 +199,22 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
     if (ok) {
       for (int k = lane; k < n_rb; k += kWave) {
         const uint32_t* d = s_words + k * kFusedRatioWords;
-        l2 = (int32_t)d[3];
+        l2 = (int32_t)(d[3] & 0x7FFFFFFFu);
         ce2 = rec_f64(d[4], d[5]);
         if (d[2] == kFusedEnd) { flags |= 2; continue; }
+        if (d[3] >> 31) flags |= 4;
         if (d[2] == kFusedNoRow) continue;
         const double ratio = rec_f64(d[0], d[1]);
         const int64_t row = (int64_t)d[2];
         if (r2 < 0 || ratio < best || (ratio == best && row < r2)) { best = ratio; r2 = row; }
       }
     }
-    flags = (ok ? 0 : 1) | (__ballot(flags & 2) ? 2 : 0);
+    flags = (ok ? 0 : 1) | (__ballot(flags & 2) ? 2 : 0) | (__ballot(flags & 4) ? 4 : 0);
     wave_arg<false>(best, r2);
     l2 = __builtin_amdgcn_readfirstlane(l2);       // lane 0 always holds a record, and every record names the same column
     ce2 = rec_f64((uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)__double_as_longlong(ce2)),
                   (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)__double_as_longlong(ce2) >> 32)));
-    if (flags == 0 && r2 >= 0) {
+    if ((flags & 3) == 0 && r2 >= 0) {
       // what hangs on the pivot row: requested together
       if (want_col_r && lane < j) s_u[lane] = ld_shared_f64(colp + (int64_t)lane * sh.lda + r2);
       if (lane == 0) {
@@ -274,15 +277,18 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
       double* __restrict__ cv = colv + (int64_t)(j & 1) * sh.lda;
       double bv = DBL_MAX, a_reg = 0.0;
       int64_t bi = -1;
+      bool big = false;
       if (kReg) {
         if (have) {
           a_reg = fused_chain_reg<true, kHist>(col[i0], j, s_u, h);
+          big = !(fabs(a_reg) < kDirtyBound);
           st_shared_f64(cv + i0, a_reg);
           if (!((float)a_reg > -1e-6f)) { bv = rhs_reg / (-a_reg); bi = i0; }
         }
       } else {
         for (int64_t i = i0; i < sh.m; i += stride) {
           const double a = fused_chain<true>(col[i], j, s_u, colp + i, sh.lda);
+          big = big || !(fabs(a) < kDirtyBound);
           st_shared_f64(cv + i, a);
           if ((float)a > -1e-6f) continue;
           const double ratio = ld_shared_f64(rhs + i) / (-a);
@@ -291,12 +297,13 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
       }
       LPAMD_CLK(j, 0, 2, blockIdx.x == 0);
       wait_stores();                      // the rebuilt column is out before the record that may name one of its rows
+      const bool any_big = __syncthreads_or(big) != 0;
       block_arg<false, kThreads>(bv, bi, s_v, s_i);
       if (publisher) {                    // every thread holds the workgroup's result
         const uint64_t vb = (uint64_t)__double_as_longlong(bv), cb2 = (uint64_t)__double_as_longlong(ce);
         const int x = tid % kFusedRatioWords;
         const uint32_t word = x == 0 ? (uint32_t)vb : x == 1 ? (uint32_t)(vb >> 32) : x == 2 ? (bi < 0 ? kFusedNoRow : (uint32_t)bi)
-                            : x == 3 ? (uint32_t)l : x == 4 ? (uint32_t)cb2 : (uint32_t)(cb2 >> 32);
+                            : x == 3 ? ((uint32_t)l | (any_big ? 0x80000000u : 0u)) : x == 4 ? (uint32_t)cb2 : (uint32_t)(cb2 >> 32);
         rec_put(mine, word, tag);
       }
       LPAMD_CLK(j, 0, 3, blockIdx.x == 0);
@@ -330,9 +337,11 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
           st_shared_f64(rhs_now + i, rp_rhs != 0.0 ? flushz(__dadd_rn(rhs_i, __dmul_rn(cpi, rp_rhs))) : rhs_i);
         }
       }
+      const bool ends_here = (s_f.flags & 4) != 0;
       wait_stores();       // col'_j and the right-hand side are out before this workgroup's next record
       __syncthreads();     // (and s_f / s_u are free again)
       LPAMD_CLK(j, 0, 5, blockIdx.x == 0);
+      if (ends_here) return;   // PivotState::dirty: no step is set up behind this one
     }
     return;
   }
@@ -369,6 +378,7 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
     LPAMD_CLK(j, 3, 1, cb == n_cb - 1);
     const double a2 = s_f.a, ce2 = s_f.ce;
     const int32_t l_e2 = s_f.l;
+    const bool ends_here = (s_f.flags & 4) != 0;
     const double f2 = -1.0 / a2;                     // lp_simplex_tableau.cc:40
     const double g2 = __dmul_rn(ce2, f2);            // lp_simplex_tableau.cc:34-35
     LPAMD_CLK(j, 2, 2, cb == 0);
@@ -446,7 +456,9 @@ __global__ __launch_bounds__(kThreads, kThreads == 256 ? 3 : kThreads == 512 ? 2
       steps[j] = z;
       const int64_t it = it0 + (j - 1);
       if (it < trace_cap) { trace[2 * it] = e2; trace[2 * it + 1] = r2; }
+      if (ends_here) st->dirty_step = j + 1;
     }
+    if (ends_here) return;   // PivotState::dirty: no step is set up behind this one
   }
 }
 

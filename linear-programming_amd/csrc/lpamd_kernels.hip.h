@@ -32,7 +32,9 @@ constexpr int kMaxPartials = 2048;
 constexpr int kWave = 64;
 
 // device-side status: 0 while running, otherwise (reference Result value + 1)
-enum : int32_t { ST_RUNNING = 0, ST_ERROR = 1, ST_UNBOUNDED = 2, ST_NOSOLUTION = 3, ST_SOLVED = 4, ST_LIMIT = 5 };
+// ST_DIRTY: the device loops stop because basic columns are no longer unit columns (see PivotState::dirty); the host goes on
+// with the loop that scans rows and columns the way the reference does.
+enum : int32_t { ST_RUNNING = 0, ST_ERROR = 1, ST_UNBOUNDED = 2, ST_NOSOLUTION = 3, ST_SOLVED = 4, ST_LIMIT = 5, ST_DIRTY = 6 };
 
 struct Candidate {   // 32 bytes, also the multi-GPU exchange record
   double key;        // MAX_COST: reduced cost c_e.  MAX_REDUCTION: c_e * min ratio
@@ -43,7 +45,12 @@ struct Candidate {   // 32 bytes, also the multi-GPU exchange record
 
 struct PivotState {  // device resident, one per engine
   int32_t status;
-  int32_t pad0;
+  // 1: the tableau may hold stored entries below the drop threshold (an uploaded right-hand side of 5e-7, say).  The
+  // reference's update adds to EVERY entry, T = flush(T + col' * row'), so its first pivot drops them all, also in
+  // columns whose row' entry is 0; from then on every stored entry is a fixed point of the drop and leaving those
+  // columns alone changes no bit.  While this flag is set the next pivot is applied the reference's way, to every
+  // column (set by the upload when it sees such an entry, cleared by the update kernel of that pivot).
+  int32_t dense_next;
   int64_t iter;      // pivots applied so far (index into the trace)
   int64_t max_iter;  // pricing reports ST_LIMIT once iter reaches this
   int64_t e, r, d;   // global ids of entering / leaving column and the pivot row
@@ -51,7 +58,19 @@ struct PivotState {  // device resident, one per engine
   int32_t n_active;  // local columns whose pivot-row entry is non-zero
   int32_t n_active2; // second counter of the two-launch loop (the counters alternate from pivot to pivot)
   int32_t l_e, l_d;  // local columns of e and d on this rank (-1: another rank's, or none)
+  // The device loops take the leaving variable of a pivot row from basis[] and test no row for "has a basic column with a
+  // non-zero entry" (reference lp_simplex_tableau.cc:215-226, 240-251), which is the reference's answer exactly as long as
+  // every basic column is a unit column.  The entering column of a pivot becomes one because its other entries cancel,
+  // T[i][e] + T[i][e] * (a * (-1/a)): exactly when a * (-1/a) == -1, else up to |T[i][e]| * 2.3e-16, which the zero drop
+  // removes unless |T[i][e]| reaches about 4e9 (netlib's 25fv47 gets there: 9.5e10 at pivot 9724, and from then on the
+  // reference's scans and basis[] disagree).  Every set-up looks at the col' it writes: an entry of kDirtyBound or more
+  // marks the step (dirty_step = step of the pass + 1); no later step of that pass is set up, the pass kernel turns the
+  // mark into `dirty`, and the first kernel of the next iteration ends the device loop with ST_DIRTY.  The host then goes
+  // on with the loop that scans like the reference (k_basic_scan_rows, k_basis_discovery) and sets dirty = 2: known.
+  int32_t dirty;
+  int32_t dirty_step;
 };
+constexpr double kDirtyBound = 4.0e9;
 
 constexpr int kMaxChain = 32;   // pivots one pass over the tableau may apply
 
@@ -419,6 +438,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pr_fold(
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
+  if (st->dirty == 1) { if (threadIdx.x == 0) st->status = ST_DIRTY; return; }
   if (st->iter >= st->max_iter) { if (threadIdx.x == 0) st->status = ST_LIMIT; return; }
   double bv;
   int64_t bi;
@@ -456,11 +476,14 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
     Tab T, Shape sh, PivotState* __restrict__ st,
     const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
     Candidate* __restrict__ cand, const double* __restrict__ xcol,
-    double* __restrict__ rv, int64_t* __restrict__ ri) {
+    double* __restrict__ rv, int64_t* __restrict__ ri, const unsigned long long* __restrict__ first_basic = nullptr) {
+  // first_basic (the loop that scans like the reference): per row the lowest basic column with a non-zero entry there, ~0
+  // if none; a row without one does not take part (reference lp_simplex_tableau.cc:215-226)
   __shared__ double s_v[kPartialThreads / kWave];
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (st->dirty == 1) { if (lead) st->status = ST_DIRTY; return; }
   if (st->iter >= st->max_iter) { if (lead) st->status = ST_LIMIT; return; }
   int64_t e;
   if (kFoldPrice) {
@@ -485,6 +508,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
   for (int64_t i = blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)gridDim.x * kPartialThreads) {
     const double a = col[i];
     if ((float)a > -1e-6f) continue;   // skips _IsZero and _IsNonNegative entries alike
+    if (first_basic && first_basic[i] == ~0ull) continue;
     const double ratio = rhs[i] / (-a);
     if (bv > ratio) { bv = ratio; bi = i; }
   }
@@ -494,6 +518,36 @@ __global__ __launch_bounds__(kPartialThreads) void k_ratio_partial(
     ri[blockIdx.x] = bi;
     if (blockIdx.x == 0) st->n_active = 0;
   }
+}
+
+// The reference's scans, for tableaux whose basic columns are no longer unit columns (PivotState::dirty).
+// MAX_COST (reference lp_simplex_tableau.cc:215-226): a row takes part in the ratio test if some basic column has a
+// non-zero entry in it, and the first such column (ascending) is the leaving variable: first_basic[i] = lowest global id
+// of a basic column with !_IsZero(T[i][col]), ~0 if none (preset by the caller).  One workgroup per local column.
+__global__ __launch_bounds__(256) void k_basic_scan_rows(Tab T, Shape sh, const uint8_t* __restrict__ is_basic,
+                                                          unsigned long long* __restrict__ first_basic) {
+  const int l = blockIdx.x;
+  if (!is_basic[l]) return;
+  const unsigned long long g = (unsigned long long)gcol_of((int64_t)l * sh.world + sh.rank, sh.N);
+  const double* __restrict__ col = T.col(l);
+  for (int64_t i = threadIdx.x; i < sh.m; i += 256)
+    if (!is_zero(col[i])) atomicMin(&first_basic[i], g);
+}
+// MAX_REDUCTION (reference lp_simplex_tableau.cc:240-251): for every basic column in ascending order the FIRST row with a
+// non-zero entry gets that column as its basic variable, later columns overwriting earlier ones: disc[row] = highest
+// global id among the basic columns whose first non-zero row it is, -1 if none (preset by the caller).
+__global__ __launch_bounds__(256) void k_basis_discovery(Tab T, Shape sh, const uint8_t* __restrict__ is_basic, long long* __restrict__ disc) {
+  __shared__ double s_v[256 / kWave];
+  __shared__ int64_t s_i[256 / kWave];
+  const int l = blockIdx.x;
+  if (!is_basic[l]) return;
+  const double* __restrict__ col = T.col(l);
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  for (int64_t i = threadIdx.x; i < sh.m; i += 256)
+    if (bi < 0 && !is_zero(col[i])) { bv = (double)i; bi = i; }
+  block_arg<false, 256>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0 && bi >= 0) atomicMax(&disc[bi], (long long)gcol_of((int64_t)l * sh.world + sh.rank, sh.N));
 }
 
 // ------------------------------------------------ pivot set-up + row gather
@@ -518,6 +572,7 @@ __device__ __forceinline__ void pivot_setup_body(
     int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
     double* __restrict__ rhs_next, uint8_t* __restrict__ cand_next, PassInfo* __restrict__ pass, double* s_v, int64_t* s_i) {
   const int64_t e = c.gcol, eo = ordinal_of(e, sh.N);
+  const bool dense = st->dense_next != 0;   // every column takes this pivot, see PivotState
   const double* __restrict__ col = xcol ? xcol : T.col(ord_local(eo, sh.world));
   LPAMD_CHECK(0, r >= 0 && r < sh.m && eo >= 0 && eo <= sh.N);
   const double a = col[r];
@@ -526,13 +581,16 @@ __device__ __forceinline__ void pivot_setup_body(
   if ((int)blockIdx.x < n_row_blocks) {
     const double* __restrict__ rhs = T.col(sh.nloc);
     const double rp_rhs = __dmul_rn(rhs[r], f);
+    bool big = false;
     for (int64_t i = (int64_t)blockIdx.x * kPartialThreads + threadIdx.x; i < sh.m; i += (int64_t)n_row_blocks * kPartialThreads) {
       const double cpi = (i == r) ? __dadd_rn(1.0, a) : col[i];   // lp_simplex_tableau.cc:41-44
+      big = big || !(fabs(cpi) < kDirtyBound);
       colp[i] = cpi;
       // right-hand side after this pivot (the update applies the same formula to the RHS replica, and
       // leaves the column alone when its row' entry is exactly 0)
-      rhs_next[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs[i], __dmul_rn(cpi, rp_rhs))) : rhs[i];
+      rhs_next[i] = (rp_rhs != 0.0 || dense) ? flushz(__dadd_rn(rhs[i], __dmul_rn(cpi, rp_rhs))) : rhs[i];
     }
+    if (big) st->dirty_step = 1;   // pivot 0 of the pass (PivotState::dirty)
     return;
   }
   // column workgroups: strided over the local columns so that any width fits kMaxPartials workgroups
@@ -556,7 +614,7 @@ __device__ __forceinline__ void pivot_setup_body(
       if (l == l_e) o = 0.0;                                     // :37
       obj[l] = o;
       rowp[l] = rp;
-      act = rp != 0.0;
+      act = rp != 0.0 || dense;
       if (l < sh.nloc) {
         const bool basic_next = l == l_e ? true : (l == l_d ? false : is_basic[l] != 0);
         const bool candidate = !basic_next && is_pos(o);
@@ -647,6 +705,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_pivot_setup_small(
   __shared__ int64_t s_i[kPartialThreads / kWave];
   if (st->status != ST_RUNNING) return;
   const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+  if (st->dirty == 1) { if (lead) st->status = ST_DIRTY; return; }
   if (st->iter >= st->max_iter) { if (lead) st->status = ST_LIMIT; return; }
   double ce;
   int64_t l;
@@ -744,11 +803,13 @@ __global__ __launch_bounds__(kUpdateThreads, 2) void k_update(   // register bud
   if (st->status != ST_RUNNING) return;
   const int n_active = slot == 1 ? st->n_active2 : st->n_active;
   if (blockIdx.x == 0 && threadIdx.x == 0) {
+    PivotState* wst = const_cast<PivotState*>(st);   // nothing in this launch reads these fields again
     if (slot >= 0) {
-      PivotState* wst = const_cast<PivotState*>(st);   // nothing in this launch reads these fields again
       if (slot == 1) wst->n_active = 0; else wst->n_active2 = 0;
       wst->iter = st->iter + 1;
     }
+    wst->dense_next = 0;   // this update reaches every column the pivot had to reach
+    if (st->dirty_step) { if (st->dirty == 0) wst->dirty = 1; wst->dirty_step = 0; }
     // bookkeeping of reference lp_simplex_tableau.cc:16-28 for the pivot set up by k_pivot_finalize
     const int64_t e = st->e, d = st->d, eo = ordinal_of(e, sh.N);
     if (ord_rank(eo, sh.world) == sh.rank) is_basic[ord_local(eo, sh.world)] = 1;
@@ -994,6 +1055,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   const double* __restrict__ rhs_prev = rhsv + (int64_t)(j - 1) * sh.lda;
   const int32_t status = st->status;
   const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
+  const int32_t dirty_step = st->dirty_step;   // 0, or the step that wrote a col' entry of kDirtyBound or more, plus one
   Candidate rec;
   rec.key = -DBL_MAX; rec.gcol = -1; rec.row = -1; rec.ce = 0.0;
   if (kSlots && slot_world <= kWave && (int)threadIdx.x < slot_world)
@@ -1028,6 +1090,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
   if (kSlots && j == 1 && keeper)   // the step records of the pass before (k_chain_ratio does this in the other loops)
     for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
   if (!prev_done) return;
+  if (dirty_step != 0 && dirty_step - 1 < j) return;   // a step before this one ends the chain (this launch's own mark is j + 1)
   if (kSlots) {
     if (slot_world <= kWave) {
       if (threadIdx.x < kWave) {
@@ -1109,14 +1172,17 @@ __global__ __launch_bounds__(kPartialThreads) void k_chain_finalize(
     double* __restrict__ rhs_now = rhsv + (int64_t)j * sh.lda;
     const double rp_rhs = __dmul_rn(rhs_r2, f2);   // row'_j of the right-hand-side column
     const int64_t stride = (int64_t)n_row_blocks * kPartialThreads;
+    bool big = false;
     for (int64_t i = i0; i < sh.m; i += stride) {
       const bool first = i == i0;
       const double ci = kRebuild ? chain_apply(ecol[i], j, colp + i, sh.lda, rowp + l_e2, rstride) : (first ? colv0 : colv[i]);
       const double rhs_i = first ? rhs0 : rhs_prev[i];
       const double cpi = (i == r2) ? __dadd_rn(1.0, a2) : ci;
+      big = big || !(fabs(cpi) < kDirtyBound);
       cj[i] = cpi;
       rhs_now[i] = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs_i, __dmul_rn(cpi, rp_rhs))) : rhs_i;
     }
+    if (big) st->dirty_step = j + 1;   // PivotState::dirty
     LPAMD_CLK(j, 1, 3, blockIdx.x == 0);
     return;
   }
@@ -1267,6 +1333,7 @@ __device__ __forceinline__ void chain_bookkeeping(PivotState* st, ChainStep* ste
   };
   flip(st->e, st->d, st->r);
   for (int s = 1; s < pass.n_steps; s++) flip(steps[s].e, steps[s].d, steps[s].r);
+  if (st->dirty_step) { if (st->dirty == 0) st->dirty = 1; st->dirty_step = 0; }
   chain_account(steps, pass);
   if (pass.n_steps > 1) {   // no other workgroup of the launch reads these fields
     const ChainStep& z = steps[pass.n_steps - 1];
@@ -1602,6 +1669,7 @@ __global__ __launch_bounds__(kWave) void k_fold_candidates(
     Candidate* __restrict__ cand) {
   if (st->status != ST_RUNNING) return;
   if (threadIdx.x != 0) return;
+  if (st->dirty == 1) { st->status = ST_DIRTY; return; }
   if (st->iter >= st->max_iter) { st->status = ST_LIMIT; return; }
   Candidate best;
   best.key = -DBL_MAX; best.gcol = -1; best.row = -1; best.ce = 0.0;

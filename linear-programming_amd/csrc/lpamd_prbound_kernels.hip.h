@@ -49,8 +49,10 @@ __device__ __forceinline__ bool prb_step_alive(const PivotState* st, const Chain
   const int32_t status = st->status;
   const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
   const int64_t iter = st->iter, max_iter = st->max_iter;
+  const int32_t dirty_step = st->dirty_step;
   if (status != ST_RUNNING) return false;
   if (!prev_done) return false;                     // the chain ended before this step
+  if (dirty_step != 0 && dirty_step - 1 < j) return false;   // a step before this one ends the chain (PivotState::dirty)
   if (j >= 1 && iter >= max_iter) return false;     // the budget ends with step j-1 (step 0 reports LIMIT itself)
   return true;
 }
@@ -104,7 +106,8 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     } else {
       // the step records of the pass before are cleared even when the budget ends with step 0 (k_chain_list counts them)
       if (j == 1) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
-      if (j == 0 && st->iter >= st->max_iter) { st->status = ST_LIMIT; go = 0; }   // as k_pr_fold does
+      if (j == 0 && st->dirty == 1) { st->status = ST_DIRTY; go = 0; }
+      else if (j == 0 && st->iter >= st->max_iter) { st->status = ST_LIMIT; go = 0; }   // as k_pr_fold does
       else if (!prb_step_alive(st, steps, j)) go = 0;
     }
     s_go = go;

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_pick_winner(
     s_w = w;
     if (blockIdx.x == 0) {
       if (kInOrder) {
-        if (st->iter >= st->max_iter) st->status = ST_LIMIT;
+        if (st->dirty == 1) st->status = ST_DIRTY;
+        else if (st->iter >= st->max_iter) st->status = ST_LIMIT;
         else if (w < 0) st->status = any ? ST_UNBOUNDED : ST_SOLVED;
         else *cand_out = best;
       } else {
@@ -527,7 +528,31 @@ int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t*
   return LPAMD_OK;
 }
 
+int run_pivots_shard_loops(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* result, int64_t* done);
 int run_pivots_shard(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
+  LP_TRY(run_pivots_shard_loops(g, s, strategy, k, result, done));
+  if (*result == ST_DIRTY - 1)   // every rank sees the same entering columns, so all of them end here together
+    return set_err(LPAMD_E_UNSUPPORTED, "basic columns are no longer unit columns (an entering column with entries of 4e9 and more): "
+                                        "the loop that takes the reference's pivots on such a tableau runs on one GPU only");
+  return LPAMD_OK;
+}
+int run_pivots_shard_loops(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* result, int64_t* done) {
+  if (strategy != LPAMD_MAX_COST && strategy != LPAMD_MAX_REDUCTION)
+    return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
+  int32_t probe = LPAMD_LIMIT;
+  LP_TRY(lpamd_poll(s.eng, &probe));           // refreshes the host view of the pivot state
+  if (s.eng->dense_first && k != 0) {
+    // The first pivot after an upload with entries below the drop threshold is applied alone and to every column
+    // (PivotState::dense_next; every rank saw the same matrix at upload, so all take this branch together).
+    int64_t d1 = 0;
+    LP_TRY(run_in_order(g, s, strategy, 1, result, &d1));
+    *done = d1;
+    if (*result != LPAMD_LIMIT || k == 1 || d1 == 0) return LPAMD_OK;
+    int64_t d2 = 0;
+    LP_TRY(run_pivots_shard_loops(g, s, strategy, k < 0 ? k : k - 1, result, &d2));
+    *done = d1 + d2;
+    return LPAMD_OK;
+  }
   if (strategy == LPAMD_MAX_COST) return run_lookahead(g, s, k, result, done);
   if (strategy == LPAMD_MAX_REDUCTION && s.eng->pr_bounds && g->chain > 1) return run_reduction_chain(g, s, k, result, done);
   if (strategy == LPAMD_MAX_REDUCTION) return run_in_order(g, s, strategy, k, result, done);

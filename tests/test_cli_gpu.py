@@ -130,3 +130,17 @@ def test_solver_cli_reads_netlib_files_as_shipped(name, strategy):
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.rstrip("\n") == case_golden(name, strategy).rstrip("\n")
+
+
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+def test_solver_cli_25fv47_from_the_compressed_file(strategy):
+    """`solver datasets/netlib/25fv47 simplex_tableau <strategy>` on the file as the reference ships it (compressed
+    netlib form), the case the reference leaves out of its tests for its run time (reference CMakeLists.txt:130): no
+    golden exists, so stdout and the pivot sequence are compared with the oracle's."""
+    want, dt = lo.solve_text(case_text("25fv47"), strategy)
+    out = subprocess.run([os.path.join(BIN, "solver"), os.path.join(GOLDEN, "netlib_compressed", "25fv47"), "simplex_tableau", strategy, "--trace"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout == want
+    got = [tuple(map(int, l.split()[1:])) for l in out.stderr.splitlines() if l.startswith("pivot ")]
+    assert got == dt.trace()

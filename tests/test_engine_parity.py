@@ -184,3 +184,111 @@ def test_update_kernel_variants_are_bit_identical(lpamd, monkeypatch, knobs, str
     assert eng.trace() == dt.trace()
     assert_same_tableau(eng, dt)
     eng.close()
+
+
+_25FV47 = {}
+
+
+def _oracle_25fv47(strategy):
+    """The largest real instance the reference ships (822 rows before bounds; 1337 x 2910 as a tableau).  The reference
+    excludes it from its own tests for its run time (reference CMakeLists.txt:130), so there is no golden output: the
+    oracle's pivot sequence is what pins the GPU here (parity with the reference itself is unpinned for this input)."""
+    if strategy not in _25FV47:
+        tab, dt = lo.from_text(case_text("25fv47"), trace_cap=1 << 17)
+        res = dt.solve(lo.STRATEGY[strategy])
+        _25FV47[strategy] = (tab, dt, res)
+    return _25FV47[strategy]
+
+
+@pytest.mark.parametrize("knobs", [{}, {"LPAMD_CHAIN": "8"}, {"LPAMD_CHAIN": "22", "LPAMD_FUSED_THREADS": "512"}], ids=["default", "chain8", "chain22"])
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+def test_25fv47_matches_oracle(lpamd, monkeypatch, strategy, knobs):
+    """Degenerate, 26 k pivots under MAX_COST (feasibility phase included): trace, every tableau entry, objective row,
+    basis flags and the extracted solution bit-equal to the oracle; with the default loop for short columns and with
+    chains of pivots forced."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    tab, dt, want = _oracle_25fv47(strategy)
+    assert want == lo.SOLVED and dt.n_pivots > 5000
+    eng = lpamd.TableauEngine(tab.m, tab.N)
+    eng.upload(tab.T, tab.obj, tab.is_basic)
+    res, n = eng.solve(lpamd.STRATEGY[strategy])
+    assert res == lpamd.SOLVED and n == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    x = eng.column_values()
+    assert np.array_equal(bits(x), bits(dt.column_values()))
+    assert bits(np.array([eng.objective_constant()]))[0] == bits(np.array([dt.obj[tab.N]]))[0]
+    eng.close()
+
+
+def _lp_with_tiny_right_hand_sides(m, n, seed):
+    """Dense feasible LP in tableau form whose right-hand side holds exact zeros (degenerate first pivots) and stored
+    entries BELOW the drop threshold (the reference keeps a right-hand side however small, reference lp.cc:180)."""
+    rng = np.random.default_rng(seed)
+    N = n + m
+    T = np.zeros((m, N + 2), order="F")
+    T[:, :n] = -(0.1 + rng.random((m, n)))
+    T[np.arange(m), n + np.arange(m)] = -1.0
+    b = (1.0 + rng.random(m)) * n
+    b[rng.choice(m, max(2, m // 8), replace=False)] = 0.0
+    tiny = rng.choice(m, max(2, m // 8), replace=False)
+    b[tiny] = np.where(rng.random(len(tiny)) < 0.5, 5e-7, 9.9e-7)
+    T[:, N] = b
+    obj = np.zeros(N + 2)
+    obj[:n] = 0.5 + rng.random(n)
+    basic = np.zeros(N + 2, dtype=np.uint8)
+    basic[n:N] = 1
+    return T, obj, basic, N
+
+
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+@pytest.mark.parametrize("m,n", [(5, 4), (40, 30), (2304, 60)])
+def test_stored_entries_below_the_drop_threshold(lpamd, strategy, m, n):
+    """The reference's update adds to every entry and drops what ends up below 1e-6, so its FIRST pivot clears an uploaded
+    right-hand side of 5e-7 even when that pivot is degenerate (pivot-row right-hand side 0, row' of the right-hand-side
+    column 0) -- a column the engine would otherwise leave alone.  Plain dense oracle (no shortcuts) against the GPU, short
+    columns (two-launch loop) and long ones (chains of pivots per pass)."""
+    T, obj, basic, N = _lp_with_tiny_right_hand_sides(m, n, 3)
+    dt = lo.DenseTableau(T, obj, basic, N)
+    eng = lpamd.TableauEngine(m, N)
+    eng.upload(T, obj, basic)
+    # first pivot alone: degenerate, and the right-hand side loses its tiny entries
+    res, done = eng.run_pivots(lpamd.STRATEGY[strategy], 1)
+    assert dt.solve(lo.STRATEGY[strategy], max_pivots=1) == lo.LIMIT and (res, done) == (lpamd.LIMIT, 1)
+    assert eng.trace() == dt.trace()
+    assert dt.T[dt.trace()[0][1], N] == 0.0, "the first pivot is meant to be degenerate"
+    assert not np.any((dt.T[:, N] != 0) & (np.abs(dt.T[:, N]) < 1e-6))
+    assert_same_tableau(eng, dt)
+    # (the plain oracle discovers the basis with an O(m * m) scan per MAX_REDUCTION pivot: a budget keeps the long columns affordable)
+    budget = 70 if (m > 1000 and strategy == "max_reduction") else -1
+    want = dt.solve(lo.STRATEGY[strategy], max_pivots=dt.n_pivots + budget if budget > 0 else -1)
+    res, npiv = eng.run_pivots(lpamd.STRATEGY[strategy], budget)
+    assert res == want and eng.pivot_count() == dt.n_pivots
+    assert eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+    # and in one go, from a fresh upload
+    dt = lo.DenseTableau(T, obj, basic, N)
+    want = dt.solve(lo.STRATEGY[strategy], max_pivots=budget)
+    eng = lpamd.TableauEngine(m, N)
+    eng.upload(T, obj, basic)
+    res, npiv = eng.run_pivots(lpamd.STRATEGY[strategy], budget)
+    assert res == want and npiv == dt.n_pivots and eng.trace() == dt.trace()
+    assert_same_tableau(eng, dt)
+    eng.close()
+
+
+@pytest.mark.parametrize("strategy", ["max_cost", "max_reduction"])
+def test_stored_entries_below_the_drop_threshold_over_shards(lpamd, strategy):
+    m, n = 300, 50
+    T, obj, basic, N = _lp_with_tiny_right_hand_sides(m, n, 5)
+    dt = lo.DenseTableau(T, obj, basic, N)
+    want = dt.solve(lo.STRATEGY[strategy])
+    g = lpamd.ShardGroup(m, N, 3, devices=[0, 0, 0], local_exchange=True)
+    g.upload(T, obj, basic)
+    res, npiv = g.solve(lpamd.STRATEGY[strategy])
+    assert res == want and npiv == dt.n_pivots and g.trace() == dt.trace()
+    Tg, og, bg = g.download()
+    assert np.array_equal(bits(Tg), bits(dt.T)) and np.array_equal(bits(og), bits(dt.obj))
+    g.close()

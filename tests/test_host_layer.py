@@ -76,6 +76,31 @@ def test_compressed_netlib_file_converts_like_its_mps(name):
     assert got == mt.mps_to_text(_path(name))
 
 
+EXTRA = sorted(n for n in os.listdir(os.path.join(GOLDEN, "netlib_extra")) if not n.endswith(".mps"))
+
+
+@pytest.mark.parametrize("name", EXTRA)
+def test_netlib_expansion_of_sections_and_notations_the_shipped_files_lack(name):
+    """RANGES, every kind of bound, exponent notation in all its forms, long mantissas, the table of repeated numbers, a
+    passed-through line and a checksum line inside a section: inputs written by tests/golden/make_netlib_extra.py, expected
+    output printed by the reference's own tools/emps.c for them."""
+    got = subprocess.check_output([os.path.join(BIN, "lp_host_probe"), "expand", os.path.join(GOLDEN, "netlib_extra", name)])
+    want = open(os.path.join(GOLDEN, "netlib_extra", name + ".mps"), "rb").read()
+    assert got == want
+    assert b"RANGES" in want and b"E-12" in want and b" MI " in want and b"E14" in want
+
+
+def test_netlib_expansion_rejects_crafted_fields(tmp_path):
+    """A field of maximal length (an index or an integer that would overflow the accumulator) and a bound kind of zero."""
+    probe = os.path.join(BIN, "lp_host_probe")
+    head = "NAME          BAD\n1 1 1 1 0 0 0 0\n%s\n"
+    for stats, body in (("0 0 0", "NROW\n" + "!" * 70 + "\n"), ("0 0 1", "," * 70 + "\n")):
+        p = tmp_path / "crafted"
+        p.write_text(head % stats + body)
+        out = subprocess.run([probe, "expand", str(p)], capture_output=True, text=True)
+        assert out.returncode == 3 and "netlib expansion" in out.stderr, out.stderr
+
+
 def test_netlib_expansion_rejects_damaged_files(tmp_path):
     data = open(os.path.join(GOLDEN, "netlib_compressed", "afiro"), "rb").read()
     lines = data.split(b"\n")
