@@ -6,30 +6,39 @@ set -e
 export TMPDIR=/tmp
 o=gpurun_out/prof_round
 rm -rf $o; mkdir -p $o
+# The chain depth is measured when an engine is created (a few passes of the pass kernel per candidate depth).  The
+# profiled runs take the depth the plain run chose and skip that probe, so that the kernel averages are those of the
+# timed region's own launches.
+depth_of() { python3 -c "import json,sys; print(json.loads([l for l in open(sys.argv[1]).read().splitlines() if l.startswith('{')][-1])['config']['pivots_per_pass'])" "$1"; }
 stats() {   # stats <name> <bench args...>: rocprofv3 kernel stats of one bench command
   local name=$1; shift
   echo "stats $name"
-  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/st_$name -- python3 bench.py --no-cpu-baseline "$@" > $o/${name}_under_rocprof.json 2>> $o/err.log
+  LPAMD_DEPTH_PROBE=0 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $o/st_$name -- python3 bench.py --no-cpu-baseline "$@" > $o/${name}_under_rocprof.json 2>> $o/err.log
   find $o/st_$name -name "*kernel_stats.csv" -exec cp {} $o/${name}_kernel_stats.csv \;
   rm -rf $o/st_$name
 }
 pmc() {     # pmc <name> <bench args...>: the two PMC passes and their reduction
   local name=$1; shift
   echo "pmc $name"
-  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 44 --warmup 22 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
-  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 44 --warmup 22 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
+  LPAMD_DEPTH_PROBE=0 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $o/pmc_fetch -- python3 bench.py --steps 44 --warmup 22 --no-cpu-baseline "$@" > $o/pmc_fetch.json 2>> $o/err.log
+  LPAMD_DEPTH_PROBE=0 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $o/pmc_write -- python3 bench.py --steps 44 --warmup 22 --no-cpu-baseline "$@" > $o/pmc_write.json 2>> $o/err.log
   python3 scripts/pmc_traffic.py $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json > $o/pmc_hbm_traffic_$name.json
   rm -rf $o/pmc_fetch $o/pmc_write $o/pmc_fetch.json $o/pmc_write.json
 }
 # the default line (with the CPU baseline) and the driver's own invocation
 timeout -k 10 300 python3 -u bench.py > $o/bench_default_m32768_n65536.json 2>> $o/err.log
 timeout -k 10 300 python3 -u bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_default_steps20_warmup5.json 2>> $o/err.log
+export LPAMD_CHAIN=$(depth_of $o/bench_default_m32768_n65536.json)
+echo "depth chosen by the probe: $LPAMD_CHAIN"
 stats bench_default_m32768_n65536
 pmc m32768_n65536
+unset LPAMD_CHAIN
 # max-reduction, same configuration
 timeout -k 10 300 python3 -u bench.py --strategy max_reduction --no-cpu-baseline > $o/bench_max_reduction_m32768_n65536.json 2>> $o/err.log
+export LPAMD_CHAIN=$(depth_of $o/bench_max_reduction_m32768_n65536.json)
 stats bench_max_reduction_m32768_n65536 --strategy max_reduction
 pmc max_reduction_m32768_n65536 --strategy max_reduction
+unset LPAMD_CHAIN
 # one pivot per pass (the roofline of a single rank-1 update), 16 per pass (the longest chain that hides under the
 # HBM time of the pass) and 32 per pass (bound by the fp64 vector rate)
 LPAMD_CHAIN=1 timeout -k 10 300 python3 -u bench.py --no-cpu-baseline > $o/bench_one_pivot_per_pass_m32768_n65536.json 2>> $o/err.log
