@@ -5,6 +5,7 @@
 #include "lpamd_kernels.hip.h"
 #include "lpamd_prbound_kernels.hip.h"
 #include "lpamd_fused_kernels.hip.h"
+#include "lpamd_prbtail_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -99,11 +100,21 @@ struct lpamd_engine {
   double* prb_ep_v = nullptr;    // [kPrbSliced * kPrbSlices] ratio partials of a short list evaluated in slices
   int64_t* prb_ep_i = nullptr;
   int32_t prb_rows = kPrbRows;   // rows the bounds are taken from
+  bool prb_carry = true;         // the cache slots outlive a pass (PrbInfo::cache_iter)
+  uint64_t tab_version = 1, prb_cache_version = 0;   // bumped by everything that writes the tableau; what the slots were last good for
+  int32_t prb_renew = 4;         // a cache slot this many steps behind is brought up to date by the pricing that reads it
   double* prb_ub = nullptr;      // [ncl] bound per candidate column
   uint8_t* prb_ucand = nullptr;  // [ncl] candidate flags
   int32_t* prb_elist = nullptr;  // [ncl] columns to evaluate exactly
   double* prb_escore = nullptr;  // [ncl] exact score ...
   int64_t* prb_erow = nullptr;   // [ncl] ... and row of the evaluated columns
+  // steps 1.. of a pass: everything behind the bounds in one launch of resident workgroups (k_prb_tail; one GPU)
+  bool prb_tail = false;
+  int32_t tail_rows = 0, tail_cols = 0;   // row / column workgroups
+  double* prb_top_u = nullptr;   // [2 * kMaxPartials] per workgroup of k_prb_bounds: largest and second largest bound
+  int32_t* prb_top_l = nullptr;  // [kMaxPartials] ... and the column of the largest
+  uint64_t* rec_tail = nullptr;  // [kFusedReplicas copies] of the slice records, then of the records of the second round
+  uint32_t tail_epoch = 0;
   PassInfo* pass = nullptr;     // what the pass kernel has to do (k_chain_list)
   int32_t* list_full = nullptr; // [ncl] columns every step of the chain touches ...
   int32_t* list_part = nullptr; // [ncl] ... and columns some steps leave alone
@@ -328,6 +339,7 @@ int probe_chain_depth(lpamd_engine* e) {
   // equal numbers streams 7 % faster than one of random numbers at 24 steps per pass (5.77 against 6.16 ms at m=32768
   // n=65536), presumably the vector units' power.  col'_s: copies of a column; row'_s: 0.001 everywhere, so that nothing
   // grows or comes near the small-magnitude threshold over the few hundred steps of the probe.
+  e->tab_version++;
   hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)e->ncl, (unsigned)((e->sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->obj,
                      e->is_basic, e->basis, e->sh, (int64_t)e->ncl, (uint64_t)12345);
   LP_TRY(check_launch("k_fill_synthetic"));
@@ -458,6 +470,7 @@ void launch_update(lpamd_engine* e, int grid, bool nt, bool fuse_pr) {
 }
 
 int enqueue_update(lpamd_engine* e, bool fuse_pr) {
+  e->tab_version++;
   e->loop_depth = 1;   // a pass with one pivot: the step records of an earlier chain do not describe it
   if (fuse_pr && e->update_slot >= 0) return set_err(LPAMD_E_STATE, "the two-launch loop has no fused max-reduction pricing");
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -620,7 +633,39 @@ int enqueue_chain_step(lpamd_engine* e, int j, const Candidate* xcand, double* x
 
 int enqueue_chain_update(lpamd_engine* e);
 
-// MAX_REDUCTION pricing of step j of a pass from bounds (seven small launches, no pass over the tableau): the
+// The first two launches of a MAX_REDUCTION pricing from bounds: the rows of the bound, then the bound of every candidate
+// column (with_top: and what k_prb_tail selects from).
+int enqueue_prb_bounds(lpamd_engine* e, int j, bool with_top, int* n_bound_blocks_out) {
+  // the slots of the pass before serve the first pricing of this one if nothing but that pass has touched the tableau since
+  const int carry = (j == 0 && e->prb_carry && e->sh.world == 1 && e->prb_use_cache && e->prb_cache_version == e->tab_version) ? 1 : 0;
+  double* pv = e->prb_v + kMaxPartials;
+  int64_t* pi = e->prb_i + kMaxPartials;
+  int64_t* pf = e->prb_i + 2 * kMaxPartials;
+#define LPAMD_LAUNCH_ROWS(KEEP)                                                                                                      \
+  hipLaunchKernelGGL(k_prb_rows<KEEP>, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, \
+                     e->rhs_next, e->colp, e->prb_rows, e->prb_renew, e->trace, e->trace_cap, e->prb_info, e->prb_c, e->pass, carry)
+  const int64_t seg_threads = kPrbRowThreads / kPrbSegments;
+  const int64_t per_thread = (e->sh.m + (int64_t)kPrbSegments * seg_threads - 1) / ((int64_t)kPrbSegments * seg_threads);   // segments of ceil(m / 128) rows, eight threads each
+  if (e->sh.m % kPrbSegments != 0 || e->sh.m < kPrbSegments) {   // uneven segments: the general kernel sizes
+    if (e->sh.m <= 256 * kPrbSegments) LPAMD_LAUNCH_ROWS(32); else LPAMD_LAUNCH_ROWS(0);
+  }
+  else if (per_thread <= 4) LPAMD_LAUNCH_ROWS(4);
+  else if (per_thread <= 8) LPAMD_LAUNCH_ROWS(8);
+  else if (per_thread <= 16) LPAMD_LAUNCH_ROWS(16);
+  else if (per_thread <= 32) LPAMD_LAUNCH_ROWS(32);
+  else LPAMD_LAUNCH_ROWS(0);
+#undef LPAMD_LAUNCH_ROWS
+  LP_TRY(check_launch("k_prb_rows"));
+  const bool cached = e->prb_use_cache;
+  const int n_bound_blocks = (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (e->sh.nloc + kWave - 1) / kWave));   // tiles of 64 columns
+  hipLaunchKernelGGL(k_prb_bounds, dim3(n_bound_blocks), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
+                     e->rowp, e->rstride, e->prb_info, e->prb_c, e->prb_renew, cached ? e->prb_cache : nullptr, e->prb_ub, e->prb_ucand, pv, pi, pf,
+                     with_top ? e->prb_top_u : nullptr, e->prb_top_l, with_top ? e->prb_top_u + kMaxPartials : nullptr);
+  *n_bound_blocks_out = n_bound_blocks;
+  return check_launch("k_prb_bounds");
+}
+
+// MAX_REDUCTION pricing of step j of a pass from bounds (six small launches, no pass over the tableau): the
 // candidate record (column, row, score) lands in `cand`.
 int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_step = true) {
   double* pv = e->prb_v + kMaxPartials;
@@ -628,18 +673,8 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_ste
   int64_t* pf = e->prb_i + 2 * kMaxPartials;
   double* rv = e->part_v + kMaxPartials;
   int64_t* ri = e->part_i + kMaxPartials;
-  if (e->sh.m <= 256 * kPrbSegments)
-    hipLaunchKernelGGL(k_prb_rows<true>, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next,
-                       e->colp, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
-  else
-    hipLaunchKernelGGL(k_prb_rows<false>, dim3(1), dim3(kPrbRowThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->chain_depth, e->rhs_next,
-                       e->colp, e->prb_rows, e->trace, e->trace_cap, e->prb_info, e->prb_c);
-  LP_TRY(check_launch("k_prb_rows"));
-  const bool cached = e->prb_use_cache;
-  const int n_bound_blocks = (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (e->sh.nloc + kWave - 1) / kWave));   // tiles of 64 columns
-  hipLaunchKernelGGL(k_prb_bounds, dim3(n_bound_blocks), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
-                     e->rowp, e->rstride, e->prb_info, e->prb_c, cached ? e->prb_cache : nullptr, e->prb_ub, e->prb_ucand, pv, pi, pf);
-  LP_TRY(check_launch("k_prb_bounds"));
+  int n_bound_blocks = 0;
+  LP_TRY(enqueue_prb_bounds(e, j, false, &n_bound_blocks));
   hipLaunchKernelGGL(k_prb_first, dim3(e->n_ratio_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->colp, e->rowp,
                      e->rstride, e->rhs_next, pv, pi, pf, n_bound_blocks, e->prb_info, rv, ri);
   LP_TRY(check_launch("k_prb_first"));
@@ -656,12 +691,37 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_ste
   return check_launch("k_prb_pick");
 }
 
+// Step j >= 1 of a pass on one GPU: rows, bounds, then exact evaluation, fold and set-up in one launch (k_prb_tail).
+int enqueue_prb_step_tail(lpamd_engine* e, int j) {
+  int n_bound_blocks = 0;
+  LP_TRY(enqueue_prb_bounds(e, j, true, &n_bound_blocks));
+  const size_t words = (size_t)kFusedReplicas * (fused_region_words(e->tail_rows + e->tail_cols, kTailEvalWords) + fused_region_words(e->tail_rows + e->tail_cols, kTailBackWords));
+  e->tail_epoch = (e->tail_epoch + 1) & 0xFFFFFFu;
+  if (e->tail_epoch == 0) {   // the launch number wrapped: no record of an old launch may carry a tag that comes round again
+    HIP_TRY(hipMemsetAsync(e->rec_tail, 0, sizeof(uint64_t) * words, e->stream));
+    e->tail_epoch = 1;
+  }
+  const int grid = e->tail_rows + e->tail_cols;
+#define LPAMD_LAUNCH_TAIL(REC)                                                                                                          \
+  hipLaunchKernelGGL(k_prb_tail<REC>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->tail_rows, e->colp, \
+                     e->rowp, e->rstride, e->rhs_next, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->prb_top_u, e->prb_top_l,   \
+                     e->prb_top_u + kMaxPartials, n_bound_blocks, e->prb_ub, e->prb_ucand, e->prb_info, e->rec_tail,                     \
+                     e->rec_tail + (size_t)kFusedReplicas * fused_region_words(grid, kTailEvalWords), e->tail_epoch)
+  if (n_bound_blocks <= kPartialThreads) LPAMD_LAUNCH_TAIL(1);
+  else if (n_bound_blocks <= 2 * kPartialThreads) LPAMD_LAUNCH_TAIL(2);
+  else if (n_bound_blocks <= 4 * kPartialThreads) LPAMD_LAUNCH_TAIL(4);
+  else LPAMD_LAUNCH_TAIL(8);
+#undef LPAMD_LAUNCH_TAIL
+  return check_launch("k_prb_tail");
+}
+
 // One pass of MAX_REDUCTION pivots: every step is priced from bounds and set up on entries rebuilt through the
 // steps before it; the pass kernel then applies the chain.
 int enqueue_prb_pass(lpamd_engine* e) {
   LP_TRY(enqueue_prb_pricing(e, 0, e->cand));
   LP_TRY(enqueue_finalize(e, false, e->cand, nullptr, -1));
   for (int j = 1; j < e->chain_depth; j++) {
+    if (e->prb_tail) { LP_TRY(enqueue_prb_step_tail(e, j)); continue; }
     LP_TRY(enqueue_prb_pricing(e, j, e->cand));
     hipLaunchKernelGGL((k_chain_finalize<false, true>), dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T,
                        e->sh, e->st, e->steps, j, nullptr, nullptr, 0, e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, nullptr,
@@ -669,7 +729,9 @@ int enqueue_prb_pass(lpamd_engine* e) {
     LP_TRY(check_launch("k_chain_finalize"));
   }
   e->price_partials_fresh = false;
-  return enqueue_chain_update(e);
+  LP_TRY(enqueue_chain_update(e));
+  e->prb_cache_version = e->tab_version;
+  return LPAMD_OK;
 }
 
 // Column shards, MAX_REDUCTION from bounds.  Step j = the pivots already set up in this pass.
@@ -731,6 +793,7 @@ int enqueue_chain_tail(lpamd_engine* e, int depth) {
 }
 
 int enqueue_chain_update(lpamd_engine* e) {
+  e->tab_version++;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->profiling) {
     if (e->ev_used + 2 > e->ev.size()) {
@@ -1133,11 +1196,36 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     HIP_TRY(hipMalloc(&e->prb_ep_i, sizeof(int64_t) * kPrbSliced * kPrbSlices));
     if (const char* env = getenv("LPAMD_PRB_ROWS")) e->prb_rows = std::max(1, std::min(kPrbRows, atoi(env)));
     if (const char* env = getenv("LPAMD_PRB_CACHE")) e->prb_use_cache = atoi(env) != 0;
+    if (const char* env = getenv("LPAMD_PRB_RENEW")) e->prb_renew = std::max(1, atoi(env));
+    if (const char* env = getenv("LPAMD_PRB_CARRY")) e->prb_carry = atoi(env) != 0;
     HIP_TRY(hipMalloc(&e->prb_ub, sizeof(double) * e->ncl));
     HIP_TRY(hipMalloc(&e->prb_ucand, e->ncl));
     HIP_TRY(hipMalloc(&e->prb_elist, sizeof(int32_t) * e->ncl));
     HIP_TRY(hipMalloc(&e->prb_escore, sizeof(double) * e->ncl));
     HIP_TRY(hipMalloc(&e->prb_erow, sizeof(int64_t) * e->ncl));
+    // k_prb_tail: every workgroup of its grid must be resident at the same time (they wait for each other's records); the
+    // grid may take three quarters of what the device holds of the kernel, and 512 workgroups at most (record polls)
+    e->prb_tail = world == 1;
+    if (const char* env = getenv("LPAMD_PRB_TAIL")) e->prb_tail = e->prb_tail && atoi(env) != 0;
+    if (e->prb_tail) {
+      int per_cu = 0, cus = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_prb_tail<8>, kPartialThreads, 0) != hipSuccess ||
+          hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+      const int64_t room = std::min<int64_t>(kTailMaxGroups, (int64_t)per_cu * cus * 3 / 4);
+      e->tail_rows = (int32_t)std::min<int64_t>(128, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
+      e->tail_cols = (int32_t)std::min<int64_t>(room - e->tail_rows, std::max<int64_t>(1, (e->ncl + kPartialThreads - 1) / kPartialThreads));
+      if (const char* env = getenv("LPAMD_TAIL_ROWS")) e->tail_rows = std::max(1, std::min(128, atoi(env)));
+      if (const char* env = getenv("LPAMD_TAIL_COLS")) e->tail_cols = std::max(1, std::min<int>((int)room - e->tail_rows, atoi(env)));
+      if (e->tail_cols < 1 || e->tail_rows + e->tail_cols < 2 * kTailCols) e->prb_tail = false;
+    }
+    if (e->prb_tail) {
+      const int grid = e->tail_rows + e->tail_cols;
+      const size_t words = (size_t)kFusedReplicas * (fused_region_words(grid, kTailEvalWords) + fused_region_words(grid, kTailBackWords));
+      HIP_TRY(hipMalloc(&e->prb_top_u, sizeof(double) * 2 * kMaxPartials));
+      HIP_TRY(hipMalloc(&e->prb_top_l, sizeof(int32_t) * kMaxPartials));
+      HIP_TRY(hipMalloc(&e->rec_tail, sizeof(uint64_t) * words));
+      HIP_TRY(hipMemsetAsync(e->rec_tail, 0, sizeof(uint64_t) * words, e->stream));
+    }
   }
   // Steps 1.. of a MAX_COST chain in one launch (k_chain_fused): one GPU, chains only.  Preferred shape: one row / one column
   // per thread (history in registers) with the smallest workgroups that keep the grid within 512 workgroups, which the
@@ -1218,9 +1306,15 @@ int lpamd_destroy(lpamd_engine* e) {
   if (!e) return LPAMD_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (e->prb_info && getenv("LPAMD_PRB_VERBOSE")) {
+    PrbInfo pi;
+    if (hipMemcpy(&pi, e->prb_info, sizeof(pi), hipMemcpyDeviceToHost) == hipSuccess)
+      fprintf(stderr, "lpamd: %lld pricings from bounds, %lld columns evaluated besides the first, %lld second rounds in k_prb_tail\n",
+              (long long)pi.priced, (long long)pi.listed, (long long)pi.tail_back);
+  }
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
   void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->ptr_full,
-                  e->rec_ratio, e->rec_price, e->first_basic, e->basis_disc, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow};
+                  e->rec_ratio, e->rec_price, e->first_basic, e->basis_disc, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow, e->prb_top_u, e->prb_top_l, e->rec_tail};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -1260,6 +1354,7 @@ int lpamd_upload(lpamd_engine* e, const double* T, int64_t ld, const double* obj
       const double x = T[g * ld + i];
       if (x != 0.0 && std::fabs(x) < (double)1e-6f) { tiny = true; break; }
     }
+  e->tab_version++;
   for (int h = 0; h < 2; h++)
     if (!hT[h].empty())
       HIP_TRY(hipMemcpyAsync(e->T.half[h], hT[h].data(), sizeof(double) * hT[h].size(), hipMemcpyHostToDevice, e->stream));
@@ -1300,6 +1395,7 @@ int lpamd_fill_synthetic(lpamd_engine* e, int64_t n_struct, uint64_t seed) {
   const Shape& sh = e->sh;
   if (n_struct <= 0 || n_struct + sh.m != sh.N)
     return set_err(LPAMD_E_ARG, "synthetic LP needs N == n_struct + m (N=%lld n=%lld m=%lld)", (long long)sh.N, (long long)n_struct, (long long)sh.m);
+  e->tab_version++;
   hipLaunchKernelGGL(k_fill_synthetic, dim3((unsigned)e->ncl, (unsigned)((sh.lda + 255) / 256)), dim3(256), 0, e->stream, e->T, e->obj,
                      e->is_basic, e->basis, sh, n_struct, seed);
   LP_TRY(check_launch("k_fill_synthetic"));
@@ -1480,6 +1576,7 @@ int lpamd_fill_column(lpamd_engine* e, int64_t col, double value) {
   e->price_partials_fresh = false;
   LP_TRY(invalidate_pr(e));
   if (!owns(e, col)) return LPAMD_OK;
+  e->tab_version++;
   hipLaunchKernelGGL(k_fill, dim3((unsigned)((e->sh.m + 255) / 256)), dim3(256), 0, e->stream, e->T.col(local_of(e, col)), e->sh.m, value);
   return check_launch("k_fill");
 }
@@ -1529,6 +1626,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   LP_TRY(lpamd_write_objective(e, tmp.data()));
   const uint8_t zero8 = 0;
   HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));   // :71
+  e->tab_version++;
   hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T.col(local_of(e, A)), m, 1.0);  // :82-86
   LP_TRY(check_launch("k_fill"));
   LP_TRY(invalidate_pr(e));
@@ -1576,6 +1674,7 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
     HIP_TRY(hipMemcpyAsync(e->is_basic + local_of(e, A), &zero8, 1, hipMemcpyHostToDevice, e->stream));
     LP_TRY(lpamd_download(e, nullptr, 0, nullptr, basic.data()));
   }
+  e->tab_version++;
   hipLaunchKernelGGL(k_fill, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, e->stream, e->T.col(local_of(e, A)), m, 0.0);  // :143
   LP_TRY(check_launch("k_fill"));
   LP_TRY(invalidate_pr(e));

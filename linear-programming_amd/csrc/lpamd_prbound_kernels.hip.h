@@ -33,6 +33,7 @@ struct PrbInfo {
   int32_t rows[kPrbRows];
   double b[kPrbRows];      // right-hand side at those rows, as the pivots set up so far leave it
   int64_t priced, listed;  // running totals: pricings done, columns they evaluated exactly besides l1
+  int64_t tail_back;       // pricings of k_prb_tail that needed the second round
   // Row cache: R changes by a few rows from one pricing of a pass to the next, and gathering a row of a column-major
   // tableau costs a 64-byte sector per column.  Every row of R is therefore gathered once, into a slot of a
   // row-major side buffer, as the steps set up until then leave it (jf of them); the pricings after that read the
@@ -41,7 +42,25 @@ struct PrbInfo {
   int32_t jf[kPrbRows];        // steps its slot already holds
   int32_t slot_row[kPrbRows];  // row a slot holds (-1: none)
   int32_t slot_jf[kPrbRows];
+  // The slots outlive the pass when nothing but that pass has changed the tableau since: the first pricing of the next
+  // pass then brings them through the steps of the pass they still lack (its col' and row' vectors are intact until
+  // the set-up of the new pass's first pivot) instead of gathering every row again (a 64-byte sector per column and
+  // row: 140 us per pass at m=32768 n=65536).  cache_iter: the pivot count at which slots + steps describe the tableau;
+  // steps_seen: steps of the pass the slots count in; both written by every k_prb_rows launch that goes ahead.
+  int64_t cache_iter;
+  int32_t steps_seen;
+  int32_t j_apply;             // steps k_prb_bounds applies in this pricing: j, or the steps of the pass before (carried)
+  int32_t carried;             // this pricing (the first of a pass) works from the slots of the pass before
+  int32_t pad_;
 };
+
+// the slots of the pass before are good for the first pricing of this pass (see PrbInfo)
+__device__ __forceinline__ bool prb_carried(const PivotState* st, const PrbInfo* info, const PassInfo* pass, int j, int carry) {
+  if (j != 0 || !carry) return false;
+  const int64_t iter = st->iter, cache_iter = info->cache_iter;
+  const int32_t seen = info->steps_seen, applied = pass->n_steps;
+  return cache_iter == iter && seen >= 1 && seen == applied;
+}
 
 // true while step j of the pass may still be set up (the same tests k_chain_ratio makes)
 __device__ __forceinline__ bool prb_step_alive(const PivotState* st, const ChainStep* steps, int j) {
@@ -76,14 +95,16 @@ __device__ __forceinline__ const double* prb_rhs(const Tab& T, const Shape& sh, 
 constexpr int kPrbCollect = 512;   // rows (b) can hold; more than that met the threshold only for short columns
 constexpr int kPrbSegments = 128;
 constexpr int kPrbRowThreads = 1024;
-template <bool kKeepRows>   // segments of at most 256 rows: see (a)
+template <int kKeep>   // values of the right-hand side a thread keeps in registers (segments of at most 8 * kKeep rows); 0: none, see (a)
 __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int depth,
-    const double* __restrict__ rhsv, const double* __restrict__ colp, int max_rows,
-    const int64_t* __restrict__ trace, int64_t trace_cap, PrbInfo* __restrict__ info, double* __restrict__ prb_c) {
+    const double* __restrict__ rhsv, const double* __restrict__ colp, int max_rows, int renew,
+    const int64_t* __restrict__ trace, int64_t trace_cap, PrbInfo* __restrict__ info, double* __restrict__ prb_c,
+    const PassInfo* __restrict__ pass, int carry) {
   __shared__ double s_seg[kPrbSegments];
   __shared__ double s_tau;
-  __shared__ int s_go, s_ncoll, s_nrecent, s_nfresh;
+  __shared__ int s_go, s_ncoll, s_nrecent, s_nfresh, s_japply;
+  __shared__ int64_t s_iter;
   __shared__ int32_t s_crow[kPrbCollect];
   __shared__ double s_cb[kPrbCollect];
   __shared__ uint8_t s_fresh[kPrbCollect];
@@ -91,14 +112,16 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
   __shared__ int32_t s_slot_row[kPrbRows], s_slot_jf[kPrbRows];
   __shared__ int64_t s_recent[kPrbRecent];
   const int tid = threadIdx.x;
+  LPAMD_CLK(j, 0, 0, true);
   // everything this kernel reads before it can start, requested by different threads at once (one round trip)
   if (tid < kPrbRecent) {
     const int64_t tq = st->iter - 1 - tid;
     s_recent[tid] = (tq >= 0 && tq < trace_cap) ? trace[2 * tq + 1] : -1;
   } else if (tid >= kWave && tid < kWave + kPrbRows) {
     const int q = tid - kWave;
-    s_slot_row[q] = j == 0 ? -1 : info->slot_row[q];
+    const int32_t row_q = info->slot_row[q];
     s_slot_jf[q] = info->slot_jf[q];
+    s_slot_row[q] = (j == 0 && !prb_carried(st, info, pass, j, carry)) ? -1 : row_q;   // otherwise step 0 starts from empty slots
   } else if (tid == 2 * kWave) {
     int go = 1;
     if (st->status != ST_RUNNING) {
@@ -111,12 +134,15 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
       else if (!prb_step_alive(st, steps, j)) go = 0;
     }
     s_go = go;
+    s_iter = st->iter;
+    s_japply = prb_carried(st, info, pass, j, carry) ? info->steps_seen : j;
     s_ncoll = 0;
     s_nfresh = 0;
     s_tau = DBL_MAX;            // fewer minima than rows wanted: every row qualifies
   }
   __syncthreads();
   if (!s_go) return;
+  LPAMD_CLK(j, 0, 1, true);
   if (tid == 0) {               // the rows of the latest pivots, the latest first, each once
     int n_recent = 0;
     for (int q = 0; q < kPrbRecent && n_recent < max_rows; q++) {
@@ -130,18 +156,17 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
   }
   const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
   // (a) eight threads per segment, all loads of a thread in flight together.  Up to 256 rows per segment (m <= 32768)
-  // a thread's 32 values stay in registers and the rows that meet the threshold are picked from them in (b); longer
-  // columns are read a second time.
+  // a thread's values (kKeep of them: 4 for m <= 4096 .. 32) stay in registers and the rows that meet the threshold are
+  // picked from them in (b); longer columns are read a second time.
   const int m32 = (int)sh.m;     // rows fit 31 bits (checked at create): 32-bit index arithmetic, a third of the instructions
   const int n_seg = min(kPrbSegments, m32);
   const int seg = (m32 + n_seg - 1) / n_seg;
   constexpr int kPerSeg = kPrbRowThreads / kPrbSegments;
-  constexpr int kKeep = 32;    // values a thread keeps
   constexpr int kLoads = 16;   // loads in flight per thread otherwise (unconditional: the index is clamped, the value masked)
-  constexpr bool keep = kKeepRows;
+  constexpr bool keep = kKeep > 0;
   const int sidx = tid / kPerSeg, sub = tid % kPerSeg;
   const int i0 = sidx * seg + sub, i1 = sidx < n_seg ? min((sidx + 1) * seg, m32) : 0;
-  double kept[kKeepRows ? kKeep : 1];
+  double kept[keep ? kKeep : 1];
   double mymin = DBL_MAX;
   if constexpr (keep) {
     if (i0 < i1) {
@@ -166,6 +191,7 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     if (sub == 0 && sidx < n_seg) s_seg[sidx] = bv;
   }
   __syncthreads();
+  LPAMD_CLK(j, 0, 2, true);
   // (b) the threshold, then the rows that meet it
   {   // rank of every segment minimum among the minima: the eight threads of a segment count a share each
     const double mine = sidx < n_seg ? s_seg[sidx] : 0.0;
@@ -183,6 +209,7 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     if (sub == 0 && sidx < n_seg && rank == max_rows - 1) s_tau = mine;
   }
   __syncthreads();
+  LPAMD_CLK(j, 0, 3, true);
   const double tau = s_tau;
   if constexpr (keep) {
     if (mymin <= tau) {        // a few threads only
@@ -210,6 +237,7 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     }
   }
   __syncthreads();
+  LPAMD_CLK(j, 0, 4, true);
   // (c) the collected rows that are not pivot rows already, ranked by (right-hand side, row)
   const int n_coll = min(s_ncoll, kPrbCollect), n_recent = s_nrecent;
   if (tid < n_coll) {
@@ -219,7 +247,26 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     if (fresh) atomicAdd(&s_nfresh, 1);
   }
   __syncthreads();
-  if (tid < n_coll && s_fresh[tid]) {
+  if (n_coll <= kPrbRowThreads / kPerSeg) {      // the usual case: eight threads share the count of a row
+    const int c = tid / kPerSeg;
+    const bool counted = c < n_coll && s_fresh[c];
+    const double mv = counted ? s_cb[c] : 0.0;
+    const int32_t mr = counted ? s_crow[c] : 0;
+    int rank = 0;
+    if (counted) {
+#pragma unroll 4
+      for (int q = tid % kPerSeg; q < n_coll; q += kPerSeg) {
+        const double ob = s_cb[q];
+        const int32_t orow = s_crow[q];
+        const bool ofresh = s_fresh[q] != 0;
+        rank += (ofresh && (ob < mv || (ob == mv && orow < mr))) ? 1 : 0;
+      }
+    }
+    rank += dpp_i32<kDppXor1>(rank);
+    rank += dpp_i32<kDppXor2>(rank);
+    rank += dpp_i32<kDppHalfMirror>(rank);
+    if (counted && tid % kPerSeg == 0 && n_recent + rank < max_rows) s_R[n_recent + rank] = mr;
+  } else if (tid < n_coll && s_fresh[tid]) {
     const double mv = s_cb[tid];
     const int32_t mr = s_crow[tid];
     int rank = 0;
@@ -233,11 +280,15 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     if (n_recent + rank < max_rows) s_R[n_recent + rank] = mr;
   }
   __syncthreads();
+  LPAMD_CLK(j, 0, 5, true);
   const int n_rows = min(max_rows, n_recent + s_nfresh);
-  for (int t = tid; t < n_rows * j; t += kPrbRowThreads) {     // independent loads, one or two per thread
+  const int ja = s_japply;
+  const bool carried = ja != j;      // only at step 0: the steps are those of the pass before
+  for (int t = tid; t < n_rows * ja; t += kPrbRowThreads) {     // independent loads, one or two per thread
     const int k = t % n_rows, sidx = t / n_rows;
     prb_c[sidx * kPrbRows + k] = colp[(int64_t)sidx * sh.lda + s_R[k]];
   }
+  LPAMD_CLK(j, 0, 6, true);
   if (tid >= kWave) return;
   // the first wavefront: lane k keeps row k of R
   const int lane = tid;
@@ -265,11 +316,25 @@ __global__ __launch_bounds__(kPrbRowThreads) void k_prb_rows(
     info->slot_row[my_slot] = (int32_t)mine;
     info->slot_jf[my_slot] = j;
   }
-  if (lane < n_rows) { info->slot[lane] = my_slot; info->jf[lane] = hit ? s_slot_jf[my_slot] : j; }
-  if (j == 0 && lane < kPrbRows && lane >= n_rows) info->slot_row[lane] = -1;   // step 0 fills slots 0..n_rows-1
+  if (lane < n_rows) { info->slot[lane] = my_slot; info->jf[lane] = hit ? s_slot_jf[my_slot] : ja; }
+  // k_prb_bounds brings a slot that is `renew` steps behind up to date (same test there), and every slot when carried
+  if (hit && (carried || j - s_slot_jf[my_slot] >= renew)) info->slot_jf[my_slot] = j;
+  if (j == 0) {                              // slots no row of R holds are empty from here on
+    unsigned taken = lane < n_rows ? 1u << my_slot : 0u;
+    taken |= (unsigned)dpp_i32<kDppXor1>((int)taken);
+    taken |= (unsigned)dpp_i32<kDppXor2>((int)taken);
+    taken |= (unsigned)dpp_i32<kDppHalfMirror>((int)taken);
+    taken |= (unsigned)dpp_i32<kDppMirror>((int)taken);
+    taken = (unsigned)__builtin_amdgcn_readlane((int)taken, 0) | (unsigned)__builtin_amdgcn_readlane((int)taken, 16) |
+            (unsigned)__builtin_amdgcn_readlane((int)taken, 32) | (unsigned)__builtin_amdgcn_readlane((int)taken, 48);
+    if (lane < kPrbRows && !((taken >> lane) & 1u)) info->slot_row[lane] = -1;
+  }
   if (lane == 0) {
     info->n_rows = n_rows; info->n_list = 0; info->l1 = -1; info->first = -1; info->s1 = -DBL_MAX;
+    info->j_apply = ja; info->carried = carried ? 1 : 0;
+    info->steps_seen = j + 1; info->cache_iter = s_iter + 1;     // as they will be once this step is set up
   }
+  LPAMD_CLK(j, 0, 7, true);
 }
 
 // basis flag of local column l after the pivots set up so far (the pass kernel flips is_basic[] later).  q_in / q_out:
@@ -295,58 +360,74 @@ constexpr int kPrbPerGroup = kPrbRows / kPrbGroups;
 __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
     Tab T, Shape sh, const PivotState* __restrict__ st, const ChainStep* __restrict__ steps, int j,
     const double* __restrict__ obj, const uint8_t* __restrict__ is_basic,
-    const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info, const double* __restrict__ prb_c,
+    const double* __restrict__ rowp, int64_t rstride, const PrbInfo* __restrict__ info, const double* __restrict__ prb_c, int renew,
     double* __restrict__ cache,         // nullptr: the rows are gathered from the tableau itself
     double* __restrict__ ub, uint8_t* __restrict__ ucand,
-    double* __restrict__ pv, int64_t* __restrict__ pi, int64_t* __restrict__ pfirst) {
+    double* __restrict__ pv, int64_t* __restrict__ pi, int64_t* __restrict__ pfirst,
+    double* __restrict__ top_u1 = nullptr, int32_t* __restrict__ top_l1 = nullptr, double* __restrict__ top_u2 = nullptr) {
   __shared__ double s_mn[kPrbGroups][kWave];
   const int lane = threadIdx.x & (kWave - 1);
+  LPAMD_CLK(j, 1, 0, blockIdx.x == 0);
   int q_in = -1, q_out = -1;     // the records of the steps so far, one per lane
   if (lane == 0) { q_in = st->l_e; q_out = st->l_d; }
   else if (lane < j) { q_in = steps[lane].l_in; q_out = steps[lane].l_out; }
-  if (!prb_step_alive(st, steps, j)) return;
-  const int n_rows = info->n_rows;
+  // requested together with the state (one round trip): the rows of this wavefront's share of R
   const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int k0 = grp * kPrbPerGroup;
-  int jf_min = j;
+  const int n_rows = info->n_rows;
+  const int ja = cache ? info->j_apply : j;      // steps applied to cached entries (the steps of the pass before when carried)
+  const bool carried = cache && info->carried != 0;
+  int32_t i_jf[kPrbPerGroup], i_row[kPrbPerGroup], i_slot[kPrbPerGroup];
+  double i_b[kPrbPerGroup];
+#pragma unroll
+  for (int k = 0; k < kPrbPerGroup; k++) { i_jf[k] = info->jf[k0 + k]; i_row[k] = info->rows[k0 + k]; i_slot[k] = info->slot[k0 + k]; i_b[k] = info->b[k0 + k]; }
+  if (!prb_step_alive(st, steps, j)) return;
+  int jf_min = ja;
   int jfs[kPrbPerGroup], slots[kPrbPerGroup], rows[kPrbPerGroup];
   bool fresh[kPrbPerGroup];      // new to R in this pricing: gathered from the tableau here and left in its cache slot
+  bool store[kPrbPerGroup];      // ... or its slot is `renew` steps and more behind: what this pricing computes goes back to the slot
   bool any_fresh = false;
   double bs[kPrbPerGroup];
 #pragma unroll
   for (int k = 0; k < kPrbPerGroup; k++) {
     const bool live = k0 + k < n_rows;
-    const int jf = live ? (cache ? info->jf[k0 + k] : 0) : j;
-    rows[k] = live ? info->rows[k0 + k] : 0;
-    fresh[k] = live && cache && jf == j;          // slots filled by earlier pricings of the pass hold fewer steps
-    jfs[k] = fresh[k] ? 0 : jf;                   // a fresh row starts from the stored entry and takes every step
-    slots[k] = live ? (cache ? info->slot[k0 + k] : rows[k]) : 0;   // slot of the cache, or the row itself
-    bs[k] = live ? info->b[k0 + k] : 0.0;
+    const int jf = live ? (cache ? i_jf[k] : 0) : ja;
+    rows[k] = live ? i_row[k] : 0;
+    fresh[k] = live && cache && jf == ja;         // slots filled by earlier pricings of the pass hold fewer steps
+    store[k] = fresh[k] || (live && cache && (carried || ja - jf >= renew));
+    jfs[k] = fresh[k] ? (carried ? ja : 0) : jf;  // a fresh row starts from the stored entry and takes every step of this pass
+    slots[k] = live ? (cache ? i_slot[k] : rows[k]) : 0;   // slot of the cache, or the row itself
+    bs[k] = live ? i_b[k] : 0.0;
     jf_min = min(jf_min, jfs[k]);
-    any_fresh = any_fresh || fresh[k];
+    any_fresh = any_fresh || store[k];
   }
+  LPAMD_CLK(j, 1, 1, blockIdx.x == 0 && jf_min >= 0);
   double bv = -DBL_MAX;
   int64_t bi = -1, fi = -1;
+  // for k_prb_tail: this workgroup's candidate with the largest bound (a candidate without a bound counts as DBL_MAX)
+  // and the second largest bound among its candidates
+  double t1 = -DBL_MAX, t2 = -DBL_MAX;
+  int32_t tl = -1;
   const int n_tiles = (sh.nloc + kWave - 1) / kWave;
   for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int l = tile * kWave + lane;
     const double c = l < sh.nloc ? obj[l] : 0.0;
     const bool cand = l < sh.nloc && !prb_basic(l, j, is_basic, q_in, q_out) && is_pos(c);
     double mn = DBL_MAX;   // no eligible row among this wavefront's rows
-    if (cand || (any_fresh && l < sh.nloc)) {      // a fresh row is cached for EVERY local column: any of them may price later
+    if (cand || (any_fresh && l < sh.nloc)) {      // a row is cached for EVERY local column: any of them may price later
       double a[kPrbPerGroup];
 #pragma unroll
       for (int k = 0; k < kPrbPerGroup; k++)
         a[k] = k0 + k >= n_rows ? 0.0 : ((cache && !fresh[k]) ? cache[(int64_t)slots[k] * sh.nloc + l] : T.col(l)[rows[k]]);
       constexpr int kBatch = 8;   // row' values fetched together: the steps depend on each other, their loads do not
-      for (int s0 = jf_min; s0 < j; s0 += kBatch) {
+      for (int s0 = jf_min; s0 < ja; s0 += kBatch) {
         double r[kBatch];
 #pragma unroll
-        for (int q = 0; q < kBatch; q++) r[q] = s0 + q < j ? rowp[(int64_t)(s0 + q) * rstride + l] : 0.0;
+        for (int q = 0; q < kBatch; q++) r[q] = s0 + q < ja ? rowp[(int64_t)(s0 + q) * rstride + l] : 0.0;
 #pragma unroll
         for (int q = 0; q < kBatch; q++) {
           const int s = s0 + q;
-          if (s >= j || r[q] == 0.0) continue;   // the update leaves the column alone in that step
+          if (s >= ja || r[q] == 0.0) continue;   // the update leaves the column alone in that step
 #pragma unroll
           for (int k = 0; k < kPrbPerGroup; k++)
             if (s >= jfs[k]) a[k] = flushz(__dadd_rn(a[k], __dmul_rn(prb_c[s * kPrbRows + k0 + k], r[q])));   // a slot holds the steps before jf
@@ -354,7 +435,7 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
       }
 #pragma unroll
       for (int k = 0; k < kPrbPerGroup; k++) {
-        if (fresh[k]) cache[(int64_t)slots[k] * sh.nloc + l] = a[k];   // as steps 0..j-1 leave it (jf = j)
+        if (store[k]) cache[(int64_t)slots[k] * sh.nloc + l] = a[k];   // as steps 0..j-1 leave it (jf = j)
         if (cand && k0 + k < n_rows && (float)a[k] <= -1e-6f) {
           const double ratio = bs[k] / (-a[k]);
           if (ratio < mn) mn = ratio;
@@ -375,15 +456,34 @@ __global__ __launch_bounds__(kPartialThreads) void k_prb_bounds(
         // The column evaluated first should have a TIGHT bound, so that its exact score rules the others out; a
         // column without a bound is listed for evaluation anyway and would make a poor yardstick.
         if (any && u > bv) { bv = u; bi = l; }
+        if (tl < 0) { t1 = u; tl = l; }
+        else if (u > t1) { t2 = t1; t1 = u; tl = l; }
+        else if (u > t2) t2 = u;
       }
     }
     __syncthreads();
   }
+  LPAMD_CLK(j, 1, 2, blockIdx.x == 0);
   if (grp == 0) {
     wave_arg<true>(bv, bi);
     double fv = fi < 0 ? 0.0 : -(double)fi;
     wave_arg<true>(fv, fi);
     if (lane == 0) { pv[blockIdx.x] = bv; pi[blockIdx.x] = bi; pfirst[blockIdx.x] = fi; }
+    if (top_u1) {
+      uint64_t key = tl >= 0 ? arg_key<true>(t1, 0) : 0;
+      uint32_t idx = tl >= 0 ? (uint32_t)tl : kNoIndex;
+      wave_best(key, idx);                                    // lowest column on equal bounds
+      const double mine = tl < 0 ? -DBL_MAX : ((uint32_t)tl == idx ? t2 : t1);
+      uint64_t key2 = mine > -DBL_MAX ? arg_key<true>(mine, 0) : 0;
+      uint32_t any_lane = (uint32_t)lane;
+      wave_best(key2, any_lane);
+      if (lane == 0) {
+        top_u1[blockIdx.x] = key ? arg_value<true>(key) : -DBL_MAX;
+        top_l1[blockIdx.x] = key ? (int32_t)idx : -1;
+        top_u2[blockIdx.x] = key2 ? arg_value<true>(key2) : -DBL_MAX;
+      }
+    }
+    LPAMD_CLK(j, 1, 3, blockIdx.x == 0);
   }
 }
 
