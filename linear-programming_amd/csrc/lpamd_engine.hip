@@ -72,6 +72,8 @@ struct lpamd_engine {
   // Several pivots per pass over the tableau (MAX_COST on one GPU, columns too long for the two-launch loop):
   // colp holds chain_depth col' vectors (lda apart), rowp chain_depth row' vectors (rstride apart)
   int32_t chain_depth = 1;      // pivots a pass may apply (1: one pivot per pass)
+  int32_t mr_depth = 1;         // the same for MAX_REDUCTION passes priced from bounds (their set-up costs four times a MAX_COST step's: deeper passes pay)
+  int32_t alloc_depth = 1;      // steps the per-step buffers hold
   int32_t loop_depth = 1;       // depth of the device loop that ran last
   int32_t slab_shape = 0;       // k_update_slab variant (0: k_update_chain)
   int32_t slab_grid = 4096;
@@ -865,7 +867,13 @@ int enqueue_iteration(lpamd_engine* e, int strategy) {
     LP_TRY(enqueue_ratio_partial(e, true, e->cand, nullptr));
     return enqueue_finalize_update(e, true, e->cand, nullptr, -1);
   }
-  if (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds) return enqueue_prb_pass(e);
+  if (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds) {
+    const int32_t keep = e->chain_depth;     // everything a pass enqueues reads the depth from here
+    e->chain_depth = e->mr_depth;
+    const int rc = enqueue_prb_pass(e);
+    e->chain_depth = keep;
+    return rc;
+  }
   LP_TRY(enqueue_pricing(e, strategy, e->cand));
   return enqueue_finalize_update(e, false, e->cand, nullptr, -1, strategy == LPAMD_MAX_REDUCTION);
 }
@@ -993,7 +1001,7 @@ int run_loop_device(lpamd_engine* e, int strategy, int64_t budget, int32_t* resu
     if (budget >= 0 && e->h_st.iter >= e->h_st.max_iter) { *result = LPAMD_LIMIT; return LPAMD_OK; }
   }
   int64_t batch = budget >= 0 ? 1024 : 8;
-  const int64_t depth = (strategy == LPAMD_MAX_COST || (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds)) ? e->chain_depth : 1;   // pivots an iteration may apply
+  const int64_t depth = strategy == LPAMD_MAX_COST ? e->chain_depth : (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds) ? e->mr_depth : 1;   // pivots an iteration may apply
   e->loop_depth = (int32_t)depth;
   for (;;) {
     int64_t todo = batch;
@@ -1138,6 +1146,12 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     probe_depth = false;
   }
   if (probe_depth) e->chain_depth = kProbeMaxDepth;
+  // MAX_REDUCTION on one GPU, HBM-sized: a step's set-up costs about 65 us against 17 for MAX_COST, and the pass kernel
+  // still gains per pivot up to 28 steps (247 us per pivot against 273 at 22, m=32768 n=65536), so those passes go
+  // deeper than the depth that keeps the pass kernel at its best fraction of the HBM peak.
+  e->mr_depth = (probe_depth && e->sh.lda % (2 * kWave) == 0) ? 28 : e->chain_depth;
+  if (const char* env = getenv("LPAMD_MR_CHAIN")) { if (e->chain_depth > 1) e->mr_depth = std::max(2, std::min(kMaxChain, atoi(env))); }
+  e->alloc_depth = std::max(e->chain_depth, e->mr_depth);
   // Measured (m=32768 n=65536): col' from L2 8.44 ms per pass of 8 pivots; in registers, 1024-row slabs x 8 columns in
   // flight 5.65 ms per pass of 16 pivots (the HBM time of one pass), x 4 columns 5.91 ms, 512-row slabs x 8 columns 6.64 ms
   // shards inside the Infinity Cache (m=4096 n=8192: 0.134 -> 0.116 ms per pass of 16 pivots) take the 512-row slabs as well: twice the workgroups
@@ -1168,16 +1182,16 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   HIP_TRY(hipMalloc(&e->is_basic, e->ncl));
   HIP_TRY(hipMalloc(&e->basis, sizeof(int64_t) * m));
   e->rstride = std::max<int64_t>(e->ncl, e->sh.lda);
-  HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda * e->chain_depth));
-  HIP_TRY(hipMalloc(&e->rowp, sizeof(double) * e->rstride * e->chain_depth));
+  HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda * e->alloc_depth));
+  HIP_TRY(hipMalloc(&e->rowp, sizeof(double) * e->rstride * e->alloc_depth));
   HIP_TRY(hipMalloc(&e->active, sizeof(int32_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
   HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
   HIP_TRY(hipMalloc(&e->pr_stamp, sizeof(int64_t) * e->ncl));
-  HIP_TRY(hipMalloc(&e->rhs_next, sizeof(double) * e->sh.lda * e->chain_depth));
+  HIP_TRY(hipMalloc(&e->rhs_next, sizeof(double) * e->sh.lda * e->alloc_depth));
   HIP_TRY(hipMalloc(&e->cand_next, e->ncl));
   HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
-  HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda * e->chain_depth, e->stream));
+  HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda * e->alloc_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
   HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
@@ -1277,8 +1291,8 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (e->chain_depth > 1) {
     HIP_TRY(hipMalloc(&e->list_full, sizeof(int32_t) * e->ncl));
     HIP_TRY(hipMalloc(&e->list_part, sizeof(int32_t) * e->ncl));
-    HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)(e->ncl + 8) * e->chain_depth));   // whole batches of up to 8 columns
-    HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->chain_depth));
+    HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)(e->ncl + 8) * e->alloc_depth));   // whole batches of up to 8 columns
+    HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->alloc_depth));
     HIP_TRY(hipMalloc(&e->ptr_full, sizeof(uint64_t) * (size_t)(e->ncl + 8)));
   }
   HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * 2 * e->sh.lda, e->stream));    // rows beyond m stay zero
@@ -1293,7 +1307,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->n_row_blocks = (int32_t)std::min<int64_t>(256, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));   // one row per thread up to 65536 rows
   if (const char* env = getenv("LPAMD_ROW_BLOCKS")) e->n_row_blocks = std::max(1, std::min(1024, atoi(env)));
   HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
-  HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * e->chain_depth, e->stream));
+  HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * e->alloc_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));
   std::memset(&e->h_st, 0, sizeof(PivotState));
   LP_TRY(ensure_trace(e, 4096));
@@ -1842,7 +1856,7 @@ int lpamd_pricing_stats(lpamd_engine* e, int64_t* pricings, int64_t* columns_eva
 
 int lpamd_loop_depth(const lpamd_engine* e, int32_t strategy, int32_t* depth) {
   if (!e || !depth) return set_err(LPAMD_E_ARG, "loop_depth: null argument");
-  *depth = ((strategy == LPAMD_MAX_COST && !e->two_launch) || (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds)) ? e->chain_depth : 1;
+  *depth = (strategy == LPAMD_MAX_COST && !e->two_launch) ? e->chain_depth : (strategy == LPAMD_MAX_REDUCTION && e->pr_bounds) ? e->mr_depth : 1;
   return LPAMD_OK;
 }
 

@@ -151,3 +151,55 @@ def test_max_reduction_unbounded_and_infeasible(lpamd):
         assert res == want and eng.trace() == dt.trace()
         assert_same_tableau(eng, dt)
         eng.close()
+
+
+def test_cache_slots_outlive_a_pass_only_while_nothing_else_writes_the_tableau(lpamd, monkeypatch, depth):
+    """The rows the bounds look at stay cached from one pass to the next.  Whatever else writes the tableau in between
+    (a column filled by hand, single pivots, passes of the other strategy, a new upload into the same engine) must make
+    the next pricing gather them again: same pivots and bits as an engine that never keeps them (LPAMD_PRB_CARRY=0)."""
+    if depth not in (5, 16):
+        pytest.skip("two depths are enough")
+    m, n, seed = 700, 1300, 9
+    keep = lpamd.TableauEngine(m, n + m)
+    monkeypatch.setenv("LPAMD_PRB_CARRY", "0")
+    fresh = lpamd.TableauEngine(m, n + m)
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    total = 0
+
+    def both(f):
+        out = [f(e) for e in (keep, fresh)]
+        assert out[0] == out[1]
+        return out[0]
+
+    both(lambda e: e.fill_synthetic(n, seed))
+    for k in (2 * depth + 3, depth, 1):
+        both(lambda e: e.run_pivots(lpamd.MAX_REDUCTION, k))
+        total += k
+    assert dt.solve(lo.MAX_REDUCTION, max_pivots=total) == lo.LIMIT
+    assert keep.trace() == fresh.trace() == dt.trace()
+    assert_same_tableau(keep, dt)
+    # a non-basic column changed by hand: the pivot count stays, the cached rows are stale
+    basic = keep.download_basic()
+    col = next(j for j in range(n) if not basic[j])
+    both(lambda e: e.fill_column(col, -0.75))
+    both(lambda e: e.run_pivots(lpamd.MAX_REDUCTION, depth + 2))
+    # a single pivot through the step-by-step entry points, then passes of the other strategy
+    e_col, row, leaving = both(lambda e: e.price_max_reduction())
+    if e_col >= 0 and row >= 0:
+        both(lambda e: e.pivot(leaving, e_col, row))
+    both(lambda e: e.run_pivots(lpamd.MAX_REDUCTION, depth + 1))
+    both(lambda e: e.run_pivots(lpamd.MAX_COST, 2 * depth + 1))
+    both(lambda e: e.run_pivots(lpamd.MAX_REDUCTION, 3 * depth))
+    assert keep.trace() == fresh.trace()
+    a, b = keep.download(), fresh.download()
+    for x, y in zip(a[:2], b[:2]):
+        assert np.array_equal(bits(x), bits(y))
+    # a new tableau in the same engines
+    both(lambda e: e.fill_synthetic(n, seed + 1))
+    dt2 = lo.DenseTableau.synthetic(m, n, seed + 1)
+    both(lambda e: e.run_pivots(lpamd.MAX_REDUCTION, 2 * depth + 1))
+    assert dt2.solve(lo.MAX_REDUCTION, max_pivots=2 * depth + 1) == lo.LIMIT
+    assert keep.trace() == fresh.trace() == dt2.trace()
+    assert_same_tableau(keep, dt2)
+    keep.close()
+    fresh.close()
