@@ -125,13 +125,17 @@ int lpamd_trace(const lpamd_engine* eng, int64_t* e, int64_t* r, int64_t cap, in
  * profiling was switched on (a launch may apply a chain of pivots, see lpamd_pass_stats). */
 int lpamd_set_profiling(lpamd_engine* eng, int32_t on);
 int lpamd_update_stats(lpamd_engine* eng, double* total_ms, int64_t* launches, int64_t* active_columns);
-/* The device loop of lpamd_run_pivots / lpamd_solve applies a chain of up to 8 MAX_COST
- * pivots per pass over the tableau (one GPU, m > 2048; LPAMD_CHAIN=1..8 overrides): the
- * column and the row of every further pivot are rebuilt from the col'/row' vectors of the
- * pivots before it (the arithmetic of reference lp_simplex_tableau.cc:33-46, entry by entry
- * in the same order), so the results are those of one pass per pivot.  For the last pass:
- * the pivots it applied, the columns it streamed, and the sum of the columns the pivots
- * touch one by one (what lpamd_update_stats reports as active_columns). */
+/* The device loop of lpamd_run_pivots / lpamd_solve applies a chain of pivots per pass over the
+ * tableau wherever a pass is bound by memory (m > 2048 on one GPU, every column shard), for both
+ * strategies: up to 32 per pass; 16 for shards that fit the last-level cache, 22 for column
+ * shards, and on one GPU with an HBM-sized tableau the depth is measured when the engine is
+ * created (17..24 for MAX_COST, 28 for MAX_REDUCTION).  LPAMD_CHAIN=1..32 sets it by hand (1: one
+ * pivot per pass), lpamd_loop_depth reports it.  The column and the row of every further pivot
+ * of a pass are rebuilt from the col'/row' vectors of the pivots before it (the arithmetic of
+ * reference lp_simplex_tableau.cc:33-46, entry by entry in the same order), so the results are
+ * those of one pass per pivot.  For the last pass: the pivots it applied, the columns it
+ * streamed, and the sum of the columns the pivots touch one by one (what lpamd_update_stats
+ * reports as active_columns). */
 int lpamd_pass_stats(lpamd_engine* eng, int32_t* pivots, int64_t* streamed_columns, int64_t* touched_columns);
 /* Totals over all passes since lpamd_set_profiling(eng, 1): milliseconds inside the update kernel (HIP events on
  * the engine's stream), passes (= launches of that kernel), pivots they applied, columns they streamed (a column

@@ -1622,11 +1622,30 @@ int lpamd_run_pivots(lpamd_engine* e, int32_t strategy, int64_t k, int32_t* resu
 // LPModel::TableauSimplexInitialize (reference lp_simplex_tableau.cc:64-171).
 // The pivots and the inner solve run on the device; the one-off scans around
 // them read single rows / columns back.
+}  // extern "C"
+
+namespace {
+// max_pivots >= 0: at most that many pivots, the explicit ones included; *result = LPAMD_LIMIT when they are used up
+// before the inner solve ends (the engine is then in the middle of the phase: auxiliary objective, artificial column).
+int phase1_budgeted(lpamd_engine* e, int32_t strategy, int64_t max_pivots, int32_t* result);
+}  // namespace
+
+extern "C" {
+
 int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   CHECK_LOADED(e);
   CHECK_NO_PENDING_UPDATE(e);
   LP_TRY(single_gpu_only(e, "lpamd_phase1"));
   if (!result) return set_err(LPAMD_E_ARG, "phase1: null result");
+  return phase1_budgeted(e, strategy, -1, result);
+}
+
+}  // extern "C"
+
+namespace {
+int phase1_budgeted(lpamd_engine* e, int32_t strategy, int64_t max_pivots, int32_t* result) {
+  LP_TRY(pull_state(e));
+  const int64_t iter0 = e->h_st.iter;
   const Shape& sh = e->sh;
   const int64_t m = sh.m, N = sh.N, A = sh.N + 1, W = N + 2;
   int32_t need = 0;
@@ -1658,12 +1677,16 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
     if (basic[j]) { d = j; break; }
   }
   if (d < 0) return LPAMD_OK;
+  if (max_pivots == 0) { *result = LPAMD_LIMIT; return LPAMD_OK; }
   LP_TRY(lpamd_pivot(e, d, A, r));
   LP_TRY(lpamd_read_column(e, N, col.data()));
   for (int64_t i = 0; i < m; i++)                                      // :106-108 (live assert upstream)
     if (!h_is_nonneg(col[i])) return LPAMD_OK;
   int32_t inner = LPAMD_ERROR;
-  LP_TRY(run_loop(e, strategy, -1, &inner));                           // :110
+  LP_TRY(pull_state(e));
+  const int64_t left = max_pivots < 0 ? -1 : std::max<int64_t>(0, max_pivots - (e->h_st.iter - iter0));
+  LP_TRY(run_loop(e, strategy, left, &inner));                         // :110
+  if (inner == LPAMD_LIMIT) { *result = LPAMD_LIMIT; return LPAMD_OK; }
   if (inner != LPAMD_SOLVED) return LPAMD_OK;                          // :111 (live assert upstream)
   double oc = 0.0;
   LP_TRY(lpamd_objective_constant(e, &oc));
@@ -1716,6 +1739,9 @@ int lpamd_phase1(lpamd_engine* e, int32_t strategy, int32_t* result) {
   *result = LPAMD_SOLVED;
   return LPAMD_OK;
 }
+}  // namespace
+
+extern "C" {
 
 int lpamd_solve(lpamd_engine* e, int32_t strategy, int64_t max_pivots, int32_t* result, int64_t* n_pivots) {
   CHECK_LOADED(e);
@@ -1726,18 +1752,24 @@ int lpamd_solve(lpamd_engine* e, int32_t strategy, int64_t max_pivots, int32_t* 
     return set_err(LPAMD_E_UNSUPPORTED, "pivoting strategy %d is not implemented for the tableau path", strategy);
   int32_t need = 0;
   LP_TRY(lpamd_need_init(e, &need));
+  int64_t left = max_pivots;          // the budget covers the feasibility phase as well
   if (need) {                                                          // reference lp_simplex_tableau.cc:174-178
+    LP_TRY(pull_state(e));
+    const int64_t iter0 = e->h_st.iter;
     int32_t r1 = LPAMD_ERROR;
-    LP_TRY(lpamd_phase1(e, strategy, &r1));
+    LP_TRY(phase1_budgeted(e, strategy, max_pivots, &r1));
     if (r1 != LPAMD_SOLVED) {
-      *result = r1 == LPAMD_NOSOLUTION ? LPAMD_NOSOLUTION : LPAMD_ERROR;
+      *result = (r1 == LPAMD_NOSOLUTION || r1 == LPAMD_LIMIT) ? r1 : LPAMD_ERROR;
+      LP_TRY(pull_state(e));
       if (n_pivots) *n_pivots = e->h_st.iter;
       return LPAMD_OK;
     }
     LP_TRY(lpamd_need_init(e, &need));
     if (need) { *result = LPAMD_ERROR; return LPAMD_OK; }              // :179
+    LP_TRY(pull_state(e));
+    if (max_pivots >= 0) left = std::max<int64_t>(0, max_pivots - (e->h_st.iter - iter0));
   }
-  LP_TRY(run_loop(e, strategy, max_pivots, result));
+  LP_TRY(run_loop(e, strategy, left, result));
   if (n_pivots) *n_pivots = e->h_st.iter;
   return LPAMD_OK;
 }

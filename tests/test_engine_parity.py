@@ -1,6 +1,8 @@
 """GPU parity: the HIP engine (through the C ABI) against the CPU oracle and the
 reference's golden outputs.  Bit-exact bar: pivot trace (e, r), every tableau
 entry, the objective row and the basis flags must be identical."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,7 @@ from oracle import lp_frontend as fe
 from oracle import lp_oracle as lo
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def bits(a):
@@ -219,6 +222,33 @@ def test_25fv47_matches_oracle(lpamd, monkeypatch, strategy, knobs):
     x = eng.column_values()
     assert np.array_equal(bits(x), bits(dt.column_values()))
     assert bits(np.array([eng.objective_constant()]))[0] == bits(np.array([dt.obj[tab.N]]))[0]
+    eng.close()
+
+
+def test_qap15_first_pivots_match_the_oracle(lpamd):
+    """datasets/plato/qap15.mps (6330 equality rows: 12660 x 34937 as a tableau, 3.5 GB).  The reference ships the input
+    without an expected output, and the whole solve takes several hundred thousand pivots, which the CPU oracle (a few
+    pivots per second at this size) cannot follow; what is pinned is the start: the pivots of the oracle's first
+    `pivot_budget` pivots (feasibility phase, reference lp_simplex_tableau.cc:64-111, then its inner solve), computed once
+    by tests/golden/make_qap15_outcome.py, against the engine's, pivot by pivot through a digest, and the objective
+    constant at that point bit for bit.  Parity with the reference itself is unpinned for this input."""
+    import hashlib
+    import json
+    from oracle import mps_to_text as mt
+    want = json.load(open(os.path.join(HERE, "golden", "plato", "qap15_oracle_outcome_max_cost.json")))
+    tab = fe.build_tableau(mt.mps_to_text(os.path.join(HERE, "golden", "plato", "qap15.mps")))
+    assert (tab.m, tab.N) == (want["m"], want["N"])
+    eng = lpamd.TableauEngine(tab.m, tab.N)
+    eng.upload(tab.T, tab.obj, tab.is_basic)
+    res, n = eng.solve(lpamd.MAX_COST, max_pivots=want["pivot_budget"])
+    assert res == lpamd.LIMIT == want["result"] and n == want["n_pivots"]
+    trace = eng.trace()
+    assert [list(p) for p in trace[:16]] == want["first_pivots"] and [list(p) for p in trace[-16:]] == want["last_pivots"]
+    h = hashlib.sha256()
+    for e, r in trace:
+        h.update(b"%d %d\n" % (e, r))
+    assert h.hexdigest() == want["trace_sha256"]
+    assert "%016x" % int(bits(np.array([eng.objective_constant()]))[0]) == want["objective_constant_bits"]
     eng.close()
 
 
