@@ -77,7 +77,8 @@ struct lpamd_engine {
   int32_t loop_depth = 1;       // depth of the device loop that ran last
   int32_t slab_shape = 0;       // k_update_slab variant (0: k_update_chain)
   int32_t slab_grid = 4096;
-  int32_t deep_batch = 0;       // > 0: k_update_deep with that many columns per batch (chains longer than 16)
+  int32_t deep_batch = 0;       // > 0: k_update_deep with that many columns per batch serves the passes of more than 16 steps
+  bool deep_any_depth = false;  // ... and the shorter ones too (LPAMD_DEEP, experiments)
   int32_t deep_grid = 0;        // workgroups of k_update_deep (0: sized from the shard, see launch_deep)
   int64_t rstride = 0;
   // steps 1.. of a MAX_COST chain set up by one launch of resident workgroups (k_chain_fused; one GPU)
@@ -335,7 +336,7 @@ int probe_chain_depth(lpamd_engine* e) {
   // as many columns as a pass streams: the non-basic ones and the right-hand side (m of the N variables are basic, and
   // their unit columns are skipped), from the front of the shard like the dense columns of a fresh tableau
   const int64_t dense = std::max<int64_t>(64, e->sh.N - e->sh.m + 2);
-  e->ncl = (int32_t)std::min<int64_t>(ncl_all, std::min<int64_t>(dense, ((int64_t)64 << 30) / col_bytes));
+  e->ncl = (int32_t)std::min<int64_t>(ncl_all, dense);   // all of them: half of a 137 GB stream read 5 % high (m=65536 n=262144; the probe then takes 1.2 s)
   const bool verbose = getenv("LPAMD_DEPTH_PROBE_VERBOSE") != nullptr;
   // Random entries, as a dense LP has them (the synthetic generator; every probed column is a structural one): a shard of
   // equal numbers streams 7 % faster than one of random numbers at 24 steps per pass (5.77 against 6.16 ms at m=32768
@@ -350,7 +351,7 @@ int probe_chain_depth(lpamd_engine* e) {
   hipLaunchKernelGGL(k_fill, dim3((unsigned)((e->rstride * kProbeMaxDepth + 255) / 256)), dim3(256), 0, e->stream, e->rowp, e->rstride * kProbeMaxDepth, 1e-3);
   LP_TRY(check_launch("k_fill"));
   int chosen = 16;
-  double chosen_frac = 0.0;
+  double chosen_frac = 0.0, fracs[kMaxChain + 1] = {0.0};
   std::vector<ChainStep> hsteps(kMaxChain);
   for (int d = kProbeMaxDepth; d >= kProbeMinDepth; d--) {
     e->chain_depth = d;
@@ -376,11 +377,19 @@ int probe_chain_depth(lpamd_engine* e) {
     e->profiling = false;
     const double frac = 2.0 * col_bytes * e->ncl / std::max(ms, 1e-6) / kProbePeakBytesPerMs;
     if (verbose) fprintf(stderr, "lpamd depth probe: %d steps per pass, %.3f ms over %d columns, %.4f of the HBM peak\n", d, ms, e->ncl, frac);
+    fracs[d] = frac;
     if (frac >= kProbeTarget && chosen_frac == 0.0) { chosen = d; chosen_frac = frac; if (!verbose) break; }
+  }
+  if (chosen_frac == 0.0) {
+    // no depth streams at the target (the longest streams stay a little below it at any depth: 0.73 at m=65536 n=262144):
+    // the deepest chain within a hundredth of the best depth's fraction
+    double best = 0.0;
+    for (int d = kProbeMinDepth; d <= kProbeMaxDepth; d++) best = std::max(best, fracs[d]);
+    for (int d = kProbeMaxDepth; d >= kProbeMinDepth; d--)
+      if (fracs[d] >= best - 0.01) { chosen = d; chosen_frac = fracs[d]; break; }
   }
   if (verbose) fprintf(stderr, "lpamd depth probe: chose %d (%.4f)\n", chosen, chosen_frac);
   e->chain_depth = chosen;
-  e->deep_batch = chosen > 16 ? e->deep_batch : 0;
   e->ncl = ncl_all;
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
   HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
@@ -809,14 +818,16 @@ int enqueue_chain_update(lpamd_engine* e) {
     e1 = e->ev[e->ev_used++];
     HIP_TRY(hipEventRecord(e0, e->stream));
   }
+  // which pass kernel: the one with col' in LDS for chains beyond the 16 steps the registers hold (the depth differs by strategy)
+  const bool deep = e->deep_batch > 0 && (e->chain_depth > 16 || e->deep_any_depth);
   hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + kListThreads - 1) / kListThreads)), dim3(kListThreads), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
-                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, e->deep_batch, e->T,
+                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, deep ? e->deep_batch : 0, e->T,
                      e->ptr_full, e->fused_pending ? 1 : 0);
   e->fused_pending = false;
   LP_TRY(check_launch("k_chain_list"));
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);
   const int grid = e->update_grid;
-  if (launch_update_deep(e)) { /* col' in LDS */ }
+  if (deep && launch_update_deep(e)) { /* col' in LDS */ }
   else if (launch_update_slab(e)) { /* col' in registers */ }
   else if (n_slabs >= 16) launch_update_chain<16>(e, grid, e->update_nt);
   else if (n_slabs >= 8) launch_update_chain<8>(e, grid, e->update_nt);
@@ -1158,8 +1169,8 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->slab_shape = (e->sh.lda % 1024 == 0 && hbm_sized) ? 4 : 1;
   if (const char* env = getenv("LPAMD_SLAB")) e->slab_shape = atoi(env);
   if (const char* env = getenv("LPAMD_SLAB_GRID")) e->slab_grid = std::max(1, atoi(env));
-  e->deep_batch = (e->chain_depth > 16 && e->sh.lda % (2 * kWave) == 0) ? 8 : 0;
-  if (const char* env = getenv("LPAMD_DEEP")) e->deep_batch = (e->chain_depth > 1 && e->sh.lda % (2 * kWave) == 0) ? atoi(env) : 0;
+  e->deep_batch = (e->alloc_depth > 16 && e->sh.lda % (2 * kWave) == 0) ? 8 : 0;
+  if (const char* env = getenv("LPAMD_DEEP")) { e->deep_batch = (e->chain_depth > 1 && e->sh.lda % (2 * kWave) == 0) ? atoi(env) : 0; e->deep_any_depth = true; }
   if (e->deep_batch != 4 && e->deep_batch != 8) e->deep_batch = 0;
   if (const char* env = getenv("LPAMD_DEEP_GRID")) e->deep_grid = std::max(0, atoi(env));
   if (hip_stream) {
@@ -1320,6 +1331,9 @@ int lpamd_destroy(lpamd_engine* e) {
   if (!e) return LPAMD_OK;
   (void)hipSetDevice(e->device);
   if (e->stream) (void)hipStreamSynchronize(e->stream);
+  if (getenv("LPAMD_STATE_VERBOSE") && e->st && pull_state(e) == LPAMD_OK)
+    fprintf(stderr, "lpamd: %lld pivots, status %d, basic columns %s\n", (long long)e->h_st.iter, (int)e->h_st.status,
+            e->h_st.dirty ? "no longer unit columns (the loop that scans rows like the reference took over)" : "unit columns");
   if (e->prb_info && getenv("LPAMD_PRB_VERBOSE")) {
     PrbInfo pi;
     if (hipMemcpy(&pi, e->prb_info, sizeof(pi), hipMemcpyDeviceToHost) == hipSuccess)

@@ -64,7 +64,7 @@ r=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('depth $d', r['value'], 'pivots/s', r['roofline']['avg_launch_ms'], 'ms/pass', r['roofline']['achieved'], 'GB/s', r['roofline']['kernel'])
 " >> $o/sweep_depth_m32768_n65536.txt
 done
-for d in 16 22 32; do
+for d in 16 22 24 28 32; do
   LPAMD_CHAIN=$d timeout -k 10 200 python3 -u bench.py --strategy max_reduction --steps $((d*4)) --warmup $d --no-cpu-baseline 2>> $o/err.log | python3 -c "
 import json,sys
 r=json.loads(sys.stdin.read().strip().splitlines()[-1])
@@ -72,6 +72,15 @@ print('max_reduction depth $d', r['value'], 'pivots/s', r['roofline']['avg_launc
 " >> $o/sweep_depth_m32768_n65536.txt
 done
 LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_reduction --strategy max_reduction --steps 256 --warmup 64
+stats bench_m4096_n8192_max_reduction --config synthetic_m4096_n8192 --strategy max_reduction --steps 960 --warmup 96
+stats bench_m4096_n8192_max_cost --config synthetic_m4096_n8192 --steps 960 --warmup 96
+# timelines of the set-up kernels from the build with wall-clock checkpoints (make dbg-clock), if it is there
+if [ -f bin_scratch/liblpamd_dbgclock.so ]; then
+  for cfg in synthetic_m32768_n65536 synthetic_m4096_n8192; do
+    LPAMD_LIBRARY=bin_scratch/liblpamd_dbgclock.so timeout -k 10 200 python3 scripts/fused_timeline.py $cfg > $o/fused_setup_timeline_${cfg#synthetic_}.txt 2>> $o/err.log
+    LPAMD_LIBRARY=bin_scratch/liblpamd_dbgclock.so timeout -k 10 200 python3 scripts/prb_timeline.py $cfg > $o/max_reduction_setup_timeline_${cfg#synthetic_}.txt 2>> $o/err.log
+  done
+fi
 python3 - <<'PY'
 import glob, json
 for f in sorted(glob.glob("gpurun_out/prof_round/*.json")):
