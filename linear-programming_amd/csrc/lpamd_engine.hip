@@ -105,6 +105,7 @@ struct lpamd_engine {
   int32_t prb_rows = kPrbRows;   // rows the bounds are taken from
   bool prb_carry = true;         // the cache slots outlive a pass (PrbInfo::cache_iter)
   uint64_t tab_version = 1, prb_cache_version = 0;   // bumped by everything that writes the tableau; what the slots were last good for
+  int32_t prb_bound_blocks = 0;  // > 0: at most that many workgroups for k_prb_bounds (each walks several tiles)
   int32_t prb_renew = 4;         // a cache slot this many steps behind is brought up to date by the pricing that reads it
   double* prb_ub = nullptr;      // [ncl] bound per candidate column
   uint8_t* prb_ucand = nullptr;  // [ncl] candidate flags
@@ -668,7 +669,8 @@ int enqueue_prb_bounds(lpamd_engine* e, int j, bool with_top, int* n_bound_block
 #undef LPAMD_LAUNCH_ROWS
   LP_TRY(check_launch("k_prb_rows"));
   const bool cached = e->prb_use_cache;
-  const int n_bound_blocks = (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (e->sh.nloc + kWave - 1) / kWave));   // tiles of 64 columns
+  int n_bound_blocks = (int)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (e->sh.nloc + kWave - 1) / kWave));   // tiles of 64 columns
+  if (e->prb_bound_blocks > 0) n_bound_blocks = std::min(n_bound_blocks, e->prb_bound_blocks);
   hipLaunchKernelGGL(k_prb_bounds, dim3(n_bound_blocks), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->obj, e->is_basic,
                      e->rowp, e->rstride, e->prb_info, e->prb_c, e->prb_renew, cached ? e->prb_cache : nullptr, e->prb_ub, e->prb_ucand, pv, pi, pf,
                      with_top ? e->prb_top_u : nullptr, e->prb_top_l, with_top ? e->prb_top_u + kMaxPartials : nullptr);
@@ -1223,6 +1225,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     if (const char* env = getenv("LPAMD_PRB_CACHE")) e->prb_use_cache = atoi(env) != 0;
     if (const char* env = getenv("LPAMD_PRB_RENEW")) e->prb_renew = std::max(1, atoi(env));
     if (const char* env = getenv("LPAMD_PRB_CARRY")) e->prb_carry = atoi(env) != 0;
+    if (const char* env = getenv("LPAMD_PRB_BOUND_BLOCKS")) e->prb_bound_blocks = std::max(0, atoi(env));
     HIP_TRY(hipMalloc(&e->prb_ub, sizeof(double) * e->ncl));
     HIP_TRY(hipMalloc(&e->prb_ucand, e->ncl));
     HIP_TRY(hipMalloc(&e->prb_elist, sizeof(int32_t) * e->ncl));
