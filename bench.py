@@ -225,7 +225,7 @@ def main():
         group.fill_synthetic(n, args.seed)
         eng = group.engine(0)
         run = lambda k: group.run_pivots(strat, k)
-        depth = group.chain()
+        depth = min(group.chain(), eng.loop_depth(strat))   # MAX_REDUCTION passes may be shorter than MAX_COST ones
         exchange = "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library"
 
     K, W = args.steps, args.warmup

@@ -127,7 +127,7 @@ int lpamd_set_profiling(lpamd_engine* eng, int32_t on);
 int lpamd_update_stats(lpamd_engine* eng, double* total_ms, int64_t* launches, int64_t* active_columns);
 /* The device loop of lpamd_run_pivots / lpamd_solve applies a chain of pivots per pass over the
  * tableau wherever a pass is bound by memory (m > 2048 on one GPU, every column shard), for both
- * strategies: up to 32 per pass; 16 for shards that fit the last-level cache, 22 for column
+ * strategies: up to 32 per pass; 16 for shards that fit the last-level cache, 26 for column
  * shards, and on one GPU with an HBM-sized tableau the depth is measured when the engine is
  * created (17..24 for MAX_COST, 28 for MAX_REDUCTION).  LPAMD_CHAIN=1..32 sets it by hand (1: one
  * pivot per pass), lpamd_loop_depth reports it.  The column and the row of every further pivot

@@ -1148,9 +1148,12 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // the peak, 3800 pivots/s).  The default is the deepest chain that keeps the pass clear of 0.70 of the peak on
   // every machine seen.  Shards that fit the Infinity Cache are bound by the set-up launches and stay at 16.
   const bool hbm_sized = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
-  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? 22 : 16);
+  // Column shards of that size chain 26: their steps carry the export and the exchange on top of the set-up (20 us per step
+  // beside 34 us of pass per pivot on a shard of 8), so the depth that pays is greater than on one GPU (rank 0 of 8: 18.7 k
+  // pivots/s at 22, 19.7 k at 26, 19.8 k at 28 and 32; of 2: 6.35 k, 6.78 k, 6.95 k), at 0.67 of the HBM peak per rank.
+  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? (world > 1 ? 26 : 22) : 16);
   // One GPU, HBM-sized shard: the depth is MEASURED on this device once everything is allocated (probe_chain_depth), from
-  // kProbeMaxDepth down; the buffers are sized for that.  Column shards keep 22: every rank must chain the same number of steps.
+  // kProbeMaxDepth down; the buffers are sized for that.  Column shards keep their constant: every rank must chain the same number of steps.
   bool probe_depth = world == 1 && hbm_sized && !e->two_launch;
   if (const char* env = getenv("LPAMD_DEPTH_PROBE")) probe_depth = probe_depth && atoi(env) != 0;
   if (const char* env = getenv("LPAMD_CHAIN")) {
@@ -1163,6 +1166,11 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // still gains per pivot up to 28 steps (247 us per pivot against 273 at 22, m=32768 n=65536), so those passes go
   // deeper than the depth that keeps the pass kernel at its best fraction of the HBM peak.
   e->mr_depth = (probe_depth && e->sh.lda % (2 * kWave) == 0) ? 28 : e->chain_depth;
+  // column shards: a MAX_REDUCTION step's cost grows with its position in the pass (six launches that each walk the steps so
+  // far); on a 3 GB shard, where the set-up outweighs the pass, 22 per pass measured faster than 26 (rank 0 of 8 of m=32768
+  // n=65536: 10.9 k against 10.0 k pivots/s), on a 21 GB shard slower (rank 0 of 8 of m=65536 n=262144: 2.70 k against 2.95 k)
+  if (world > 1 && hbm_sized && !getenv("LPAMD_CHAIN") && (double)e->sh.lda * (double)e->ncl * sizeof(double) < 8e9)
+    e->mr_depth = std::min(e->chain_depth, 22);
   if (const char* env = getenv("LPAMD_MR_CHAIN")) { if (e->chain_depth > 1) e->mr_depth = std::max(2, std::min(kMaxChain, atoi(env))); }
   e->alloc_depth = std::max(e->chain_depth, e->mr_depth);
   // Measured (m=32768 n=65536): col' from L2 8.44 ms per pass of 8 pivots; in registers, 1024-row slabs x 8 columns in

@@ -225,6 +225,7 @@ struct lpamd_group {
   bool inline_exchange = true;    // collectives inside a chain run on the engine's stream (nothing to overlap them with)
   bool fused_step = true;         // MAX_COST steps inside a chain: ratio-test partials travel with the slot, two launches per step
   int chain = 1;                  // pivots per pass of the look-ahead loop
+  int chain_mr = 1;               // ... and of the MAX_REDUCTION loop
   int poll_every = 64;
   std::vector<lpamd_shard> shards;           // the shards this process holds
   std::vector<const void*> pub;              // in-process exchange: what every rank offers
@@ -487,6 +488,13 @@ int run_in_order(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* resul
 // the winner is set up on entries rebuilt through the pivots before it: a chain of pivots per pass here too.
 int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done) {
   lpamd_engine* e = s.eng;
+  // everything a pass enqueues reads the depth from the engine: a pass of fewer steps than the engine's depth would take
+  // the step-by-step path of the pass kernel
+  struct DepthGuard {
+    lpamd_engine* e; int32_t keep;
+    ~DepthGuard() { e->chain_depth = keep; }
+  } guard{e, e->chain_depth};
+  e->chain_depth = std::min<int32_t>(e->chain_depth, g->chain_mr);
   int64_t start = 0;
   LP_TRY(lpamd_pivot_count(e, &start));
   if (k == 0) { *result = LPAMD_LIMIT; *done = 0; return LPAMD_OK; }
@@ -496,9 +504,9 @@ int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t*
   int32_t res = LPAMD_LIMIT;
   for (;;) {
     const int64_t n = k < 0 ? g->poll_every : std::min<int64_t>(g->poll_every, k - enqueued);
-    const int64_t passes = (n + g->chain - 1) / g->chain;
+    const int64_t passes = (n + g->chain_mr - 1) / g->chain_mr;
     for (int64_t p = 0; p < passes; p++) {
-      for (int j = 0; j < g->chain; j++) {
+      for (int j = 0; j < g->chain_mr; j++) {
         LP_TRY(prb_shard_price(e, s.slot, kSlotHeaderWords));
         LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
         if (j == 0) {   // the fold settles budget / optimum / unbounded and keeps the winner in the engine's candidate
@@ -517,7 +525,7 @@ int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t*
       }
       LP_TRY(lpamd_lookahead_update(e));
     }
-    enqueued += passes * g->chain;
+    enqueued += passes * g->chain_mr;
     LP_TRY(lpamd_poll(e, &res));
     if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
   }
@@ -736,6 +744,9 @@ int finish_group(Group* g) {
   LP_TRY(lpamd_chain_depth(g->shards[0].eng, &depth));
   g->chain = depth;
   if (const char* env = getenv("LPAMD_SHARD_CHAIN")) g->chain = std::max(1, std::min(depth, atoi(env)));
+  int32_t depth_mr = depth;
+  LP_TRY(lpamd_loop_depth(g->shards[0].eng, LPAMD_MAX_REDUCTION, &depth_mr));
+  g->chain_mr = std::max(1, std::min<int>(g->chain, depth_mr));
   return LPAMD_OK;
 }
 
