@@ -6,6 +6,7 @@
 #include "lpamd_prbound_kernels.hip.h"
 #include "lpamd_fused_kernels.hip.h"
 #include "lpamd_prbtail_kernels.hip.h"
+#include "lpamd_shardstep_kernels.hip.h"
 
 #include <algorithm>
 #include <cmath>
@@ -119,6 +120,10 @@ struct lpamd_engine {
   int32_t* prb_top_l = nullptr;  // [kMaxPartials] ... and the column of the largest
   uint64_t* rec_tail = nullptr;  // [kFusedReplicas copies] of the slice records, then of the records of the second round
   uint32_t tail_epoch = 0;
+  // column shards, MAX_COST: set-up of a chained step and this rank's slot for the next one in one launch (k_shard_step)
+  bool shard_step = false;
+  uint64_t* rec_shard = nullptr; // [kFusedReplicas copies][fused_region_words(n_price_part, kShardRecWords)]
+  uint32_t shard_epoch = 0;
   PassInfo* pass = nullptr;     // what the pass kernel has to do (k_chain_list)
   int32_t* list_full = nullptr; // [ncl] columns every step of the chain touches ...
   int32_t* list_part = nullptr; // [ncl] ... and columns some steps leave alone
@@ -1328,6 +1333,21 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
   e->n_row_blocks = (int32_t)std::min<int64_t>(256, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));   // one row per thread up to 65536 rows
   if (const char* env = getenv("LPAMD_ROW_BLOCKS")) e->n_row_blocks = std::max(1, std::min(1024, atoi(env)));
+  // k_shard_step: one row per thread in the row workgroups, few enough column workgroups for one poll, and the whole grid
+  // resident at once (the row workgroups wait for the column workgroups)
+  e->shard_step = world > 1 && e->chain_depth > 1 && (int64_t)e->n_row_blocks * kPartialThreads >= m && e->n_price_part <= kShardMaxColGroups;
+  if (const char* env = getenv("LPAMD_SHARD_STEP")) e->shard_step = e->shard_step && atoi(env) != 0;
+  if (e->shard_step) {
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shard_step, kPartialThreads, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+    if ((int64_t)(e->n_row_blocks + e->n_price_part) * 4 > (int64_t)per_cu * cus * 3) e->shard_step = false;
+  }
+  if (e->shard_step) {
+    const size_t words = (size_t)kFusedReplicas * fused_region_words(e->n_price_part, kShardRecWords);
+    HIP_TRY(hipMalloc(&e->rec_shard, sizeof(uint64_t) * words));
+    HIP_TRY(hipMemsetAsync(e->rec_shard, 0, sizeof(uint64_t) * words, e->stream));
+  }
   HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
   HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * e->alloc_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));
@@ -1353,7 +1373,7 @@ int lpamd_destroy(lpamd_engine* e) {
   }
   for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
   void* ptrs[] = {e->T.half[0], e->T.half[1], e->obj, e->is_basic, e->basis, e->colp, e->rowp, e->active, e->cmin, e->crow, e->pr_stamp, e->rhs_next, e->cand_next, e->cand, e->cand_la, e->part_v, e->part_i, e->st, e->trace, e->steps, e->colv, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->ptr_full,
-                  e->rec_ratio, e->rec_price, e->first_basic, e->basis_disc, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow, e->prb_top_u, e->prb_top_l, e->rec_tail};
+                  e->rec_ratio, e->rec_price, e->first_basic, e->basis_disc, e->prb_info, e->prb_c, e->prb_cache, e->prb_v, e->prb_i, e->prb_ep_v, e->prb_ep_i, e->prb_ub, e->prb_ucand, e->prb_elist, e->prb_escore, e->prb_erow, e->prb_top_u, e->prb_top_l, e->rec_tail, e->rec_shard};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (e->own_stream) (void)hipStreamDestroy(e->stream);
@@ -2114,6 +2134,28 @@ int export_lookahead_ratio(lpamd_engine* e, uint64_t* slot, int header_words) {
                      e->n_price_part, reinterpret_cast<Candidate*>(slot), e->colp, e->rowp, e->rstride, e->steps,
                      e->update_pending ? e->pending_steps : 0, col, e->rhs_next, rpv, reinterpret_cast<int64_t*>(rpv + n_parts));
   return check_launch("k_export_lookahead");
+}
+
+// The two together: set-up of step `pending_steps` from the gathered slots and, into `next_slot` (nullptr: none), this rank's
+// slot for the step after it (k_shard_step).  False in *done when the engine cannot run it (see lpamd_create).
+int chain_step_export_from_slots(lpamd_engine* e, const uint64_t* slots, int world, int64_t slot_words, int header_words, uint64_t* next_slot) {
+  if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain step: no pivot has been set up by lpamd_lookahead_setup");
+  if (e->pending_steps >= e->chain_depth) return set_err(LPAMD_E_STATE, "chain step: the pass already holds %d pivots", e->pending_steps);
+  e->apply_since_pull++;
+  LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
+  e->shard_epoch = (e->shard_epoch + 1) & 0xFFFFFFu;
+  if (e->shard_epoch == 0) {   // the launch number wrapped: no record of an old launch may carry a tag that comes round again
+    HIP_TRY(hipMemsetAsync(e->rec_shard, 0, sizeof(uint64_t) * (size_t)kFusedReplicas * fused_region_words(e->n_price_part, kShardRecWords), e->stream));
+    e->shard_epoch = 1;
+  }
+  hipLaunchKernelGGL(k_shard_step, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps,
+                     e->pending_steps, (int)slot_ratio_parts(e), e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, e->obj, e->is_basic,
+                     e->basis, e->trace, e->trace_cap, e->part_v, e->part_i, slots, world, slot_words, header_words, e->chain_depth, next_slot,
+                     e->rec_shard, e->shard_epoch);
+  LP_TRY(check_launch("k_shard_step"));
+  e->price_partials_fresh = true;
+  e->pending_steps++;
+  return LPAMD_OK;
 }
 
 // ... and the set-up of that pivot on every rank straight from the gathered slots (no fold kernel, no ratio-test launch).

@@ -420,6 +420,14 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
     for (int64_t p = 0; p < passes; p++) {
       HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));
       LP_TRY(lpamd_lookahead_setup(e, s.xbuf));
+      if (g->fused_step && e->shard_step && g->chain > 1) {
+        // one launch and the collective per step: the set-up of step j also leaves this rank's slot for step j+1
+        LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));
+        for (int j = 1; j < g->chain; j++) {
+          LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
+          LP_TRY(chain_step_export_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords, j + 1 < g->chain ? s.slot : nullptr));
+        }
+      } else
       for (int j = 1; j < g->chain; j++) {
         if (g->fused_step) {   // export with ratio-test partials, all-gather, set-up straight from the slots
           LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));

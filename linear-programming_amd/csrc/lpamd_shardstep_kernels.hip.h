@@ -1,0 +1,237 @@
+// Column shards, MAX_COST, a step inside a chain: the set-up of step j from the gathered slots AND this rank's slot for
+// step j+1, in ONE launch.
+//
+// Between two collectives a chained step used to be two launches: k_chain_finalize<slots> (set-up of step j from what
+// the all-gather delivered) and k_export_lookahead<ratio> (this rank's candidate for step j+1: record, column as steps
+// 0..j will leave it, ratio-test partials on it).  The second needs what the first produces in two different sets of
+// workgroups: the pricing result of the column workgroups (which local column is the candidate, row'_j of it) and
+// col'_j / the right-hand side after the step, which the row workgroups write.  Here the row workgroups stay resident
+// behind their own part of the set-up, wait for the column workgroups' pricing results, which arrive as tagged records
+// (see lpamd_fused_kernels.hip.h: data + tag per word, agent-scope accesses, no barrier), and write the slot from the
+// col'_j and right-hand-side entries they still hold in registers: one launch and the collective per step.
+//
+// The records are published by workgroups that never wait for anybody, so the launch drains whatever the order in which
+// its workgroups start; a poll that does not complete within kFusedSpinLimit rounds marks the state ST_ERROR.  The
+// state that decides whether the step exists is not written by this launch except by its last writer's own fields (the
+// pivot count travels to the row workgroups inside the first column workgroup's record).
+#pragma once
+#include "lpamd_fused_kernels.hip.h"
+
+namespace lpamd {
+
+constexpr int kShardRecWords = 5;        // reduced cost (2), local column (1), pivot count after the step (2; first column workgroup)
+constexpr int kShardMaxColGroups = 384;  // their records are polled by 256 threads, 8 words each at most
+
+__global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
+    Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int n_ratio_part, int n_row_blocks,
+    double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, double* __restrict__ rhsv,
+    double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
+    int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
+    const uint64_t* __restrict__ slots, int slot_world, int64_t slot_words, int slot_header, int depth,
+    uint64_t* __restrict__ my_slot,      // nullptr: no slot for a next step (last step of the pass)
+    uint64_t* __restrict__ rec, uint32_t epoch) {
+  constexpr int kThreads = kPartialThreads;
+  __shared__ double s_v[kThreads / kWave];
+  __shared__ int64_t s_i[kThreads / kWave];
+  __shared__ int s_w;
+  __shared__ int64_t s_e2;
+  __shared__ double s_ce2;
+  __shared__ uint32_t s_words[8 * kThreads];
+  __shared__ __attribute__((aligned(16))) double s_u[kMaxChain];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1);
+  const bool row_block = (int)blockIdx.x < n_row_blocks;
+  const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
+  const int ncl = sh.nloc + 1;
+  const uint32_t tag = (epoch << 8) | 1u;
+  const int64_t region = fused_region_words(n_cb, kShardRecWords);
+  const double* __restrict__ rhs_prev = rhsv + (int64_t)(j - 1) * sh.lda;
+  // ---- requested before the first wait (as in k_chain_finalize): the gating state, the exchange records (one per lane of
+  // the first wavefront), the step records (one per lane), the entries of the row or column this thread owns
+  const int32_t status = st->status;
+  const int32_t prev_done = j > 1 ? steps[j - 1].done : 1;
+  const int32_t dirty_step = st->dirty_step;
+  const int64_t max_iter = st->max_iter;
+  Candidate c_rec;
+  c_rec.key = -DBL_MAX; c_rec.gcol = -1; c_rec.row = -1; c_rec.ce = 0.0;
+  if (slot_world <= kWave && tid < slot_world) c_rec = *reinterpret_cast<const Candidate*>(slots + (size_t)tid * slot_words);
+  int32_t q_in = -1, q_out = -1;
+  int64_t q_e = -1, q_r = -1;
+  if (lane == 0) { q_in = st->l_e; q_out = st->l_d; q_e = st->e; q_r = st->r; }
+  else if (lane < j) { q_in = steps[lane].l_in; q_out = steps[lane].l_out; q_e = steps[lane].e; q_r = steps[lane].r; }
+  const int64_t i0 = (int64_t)blockIdx.x * kThreads + tid;         // row workgroups: one row per thread (the host checks m)
+  const bool have_row = row_block && i0 < sh.m;
+  const double rhs0 = have_row ? rhs_prev[i0] : 0.0;
+  if (status != ST_RUNNING) return;
+  const bool keeper = cb == 0 && tid == 0;
+  if (j == 1 && keeper) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
+  if (!prev_done) return;
+  if (dirty_step != 0 && dirty_step - 1 < j) return;
+  // ---- the winner among the ranks' records (larger key, lower global column; reference lp_simplex_tableau.cc:188-198)
+  if (slot_world <= kWave) {
+    if (tid < kWave) {
+      const bool valid = c_rec.gcol >= 0;
+      double bk = valid ? c_rec.key : -DBL_MAX;
+      const int64_t gc = valid ? c_rec.gcol : -1;
+      int64_t bg = gc;
+      wave_arg<true>(bk, bg);
+      const unsigned long long owner = __ballot(gc >= 0 && gc == bg);
+      const int w = bg < 0 ? -1 : __ffsll((long long)owner) - 1;
+      if (lane == 0) s_w = w;
+      if (lane == w) { s_e2 = c_rec.gcol; s_ce2 = c_rec.ce; }
+    }
+  } else if (tid == 0) {
+    int w = -1;
+    Candidate best = c_rec;
+    for (int k = 0; k < slot_world; k++) {
+      const Candidate c = *reinterpret_cast<const Candidate*>(slots + (size_t)k * slot_words);
+      if (c.gcol < 0) continue;
+      if (w < 0 || c.key > best.key || (c.key == best.key && c.gcol < best.gcol)) { w = k; best = c; }
+    }
+    s_w = w; s_e2 = best.gcol; s_ce2 = best.ce;
+  }
+  __syncthreads();
+  const int w = s_w;
+  if (w < 0) return;                      // optimal after step j-1, or the budget ends with it
+  const uint64_t* __restrict__ mine = slots + (size_t)w * slot_words;
+  const int64_t e2 = s_e2;
+  const double ce2 = s_ce2;
+  const double* __restrict__ colv = reinterpret_cast<const double*>(mine + slot_header);
+  const double* __restrict__ rv = colv + sh.lda;      // the owner's ratio-test partials: values, then rows
+  const int64_t* __restrict__ ri = reinterpret_cast<const int64_t*>(rv + n_ratio_part);
+  const double colv0 = have_row ? colv[i0] : 0.0;
+  double best = DBL_MAX;
+  int64_t r2 = -1;
+  fold_share<false, kThreads>(rv, ri, n_ratio_part, best, r2);
+  block_arg<false, kThreads>(best, r2, s_v, s_i);
+  if (r2 < 0) return;                     // unbounded after step j-1: found again, and reported, by the next iteration
+  r2 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r2 >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r2));
+  auto local_id = [&](int64_t g) -> int {
+    if (g < 0 || g == sh.N) return -1;
+    const int64_t o = ordinal_of(g, sh.N);
+    return (ord_rank(o, sh.world) == sh.rank) ? ord_local(o, sh.world) : -1;
+  };
+  const int l_e2 = local_id(e2);
+  const double a2 = colv[r2];
+  const double f2 = -1.0 / a2;
+  const double g2 = __dmul_rn(ce2, f2);
+
+  if (row_block) {
+    // ---- col'_j and the right-hand side after the step for this thread's row
+    double cpi = 0.0, rhs_i = 0.0;
+    if (have_row) {
+      const double rp_rhs = __dmul_rn(rhs_prev[r2], f2);   // row'_j of the right-hand-side column
+      cpi = (i0 == r2) ? __dadd_rn(1.0, a2) : colv0;      // lp_simplex_tableau.cc:41-44
+      rhs_i = rp_rhs != 0.0 ? flushz(__dadd_rn(rhs0, __dmul_rn(cpi, rp_rhs))) : rhs0;
+      colp[(int64_t)j * sh.lda + i0] = cpi;
+      rhsv[(int64_t)j * sh.lda + i0] = rhs_i;
+      if (!(fabs(cpi) < kDirtyBound)) st->dirty_step = j + 1;   // PivotState::dirty
+    }
+    if (!my_slot) return;
+    // ---- this rank's slot for step j+1.  While the column workgroups are at work: col'_s of this thread's row for the
+    // steps so far, into registers (they do not depend on which column the candidate will be)
+    double h[kMaxChain];
+#pragma unroll
+    for (int s0 = 0; s0 < kMaxChain; s0 += 4) {
+      if (s0 < j) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[s0 + q] = (s0 + q < j && have_row) ? colp[(int64_t)(s0 + q) * sh.lda + i0] : 0.0;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) h[s0 + q] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int s = 1; s < kMaxChain; s++) if (s == j) h[s] = cpi;
+    // The pricing after step j: the column workgroups' records
+    const bool ok = poll_words<8>(rec + (int64_t)((int)blockIdx.x % kFusedReplicas) * region, n_cb * kShardRecWords, tag, tid, kThreads, s_words);
+    if (__syncthreads_or(!ok)) { if (tid == 0) st->status = ST_ERROR; return; }
+    double ce = -DBL_MAX;
+    int64_t lw = -1;
+    for (int k = tid; k < n_cb; k += kThreads) {
+      const uint32_t* d = s_words + k * kShardRecWords;
+      take_max(ce, lw, rec_f64(d[0], d[1]), (int64_t)(int32_t)d[2]);
+    }
+    const int64_t iter_after = (int64_t)(((uint64_t)s_words[4] << 32) | s_words[3]);
+    block_arg<true, kThreads>(ce, lw, s_v, s_i);
+    if (iter_after >= max_iter) lw = -1;           // a used-up budget travels as "no candidate"
+    if (blockIdx.x == 0 && tid == 0) {
+      Candidate c;
+      c.key = ce; c.ce = ce; c.row = -1;
+      c.gcol = lw < 0 ? -1 : gcol_of(lw * sh.world + sh.rank, sh.N);
+      *reinterpret_cast<Candidate*>(my_slot) = c;
+    }
+    double* __restrict__ xlocal = reinterpret_cast<double*>(my_slot + slot_header);
+    double* __restrict__ rpart_v = xlocal + sh.lda;
+    int64_t* __restrict__ rpart_i = reinterpret_cast<int64_t*>(rpart_v + n_ratio_part);
+    // the candidate column as steps 0..j will leave it: steps 0..j-1 from what the launches before left, step j from the
+    // col' entry this thread has just computed and the row' entry its column workgroup has just written
+    double v = 0.0;
+    const int l = lw >= 0 ? __builtin_amdgcn_readfirstlane((int)lw) : 0;
+    const double t0 = (lw >= 0 && have_row) ? T.col(l)[i0] : 0.0;
+    if (lw >= 0 && tid <= j) s_u[tid] = ld_shared_f64(rowp + (int64_t)tid * rstride + l);   // row'_s of the candidate, one round trip
+    __syncthreads();
+    if (lw >= 0 && have_row) v = fused_chain_reg<true, kMaxChain>(t0, j + 1, s_u, h);
+    if (i0 < sh.lda) xlocal[i0] = v;
+    double bv = DBL_MAX;
+    int64_t bi = -1;
+    if (lw >= 0 && have_row && (float)v <= -1e-6f) { bv = rhs_i / (-v); bi = i0; }   // reference lp_simplex_tableau.cc:207-227
+    block_arg<false, kThreads>(bv, bi, s_v, s_i);
+    if (tid == 0) { rpart_v[blockIdx.x] = bv; rpart_i[blockIdx.x] = bi; }
+    return;
+  }
+
+  // ---- column workgroups: the pivot row through the steps so far, row'_j, the objective row, the pricing after the step
+  int64_t d2 = basis[r2];
+  {
+    const unsigned long long hit = __ballot(lane < j && q_r == r2);
+    if (hit) d2 = readlane_i64(q_e, 63 - __clzll((long long)hit));
+  }
+  const int l_d2 = local_id(d2);
+  const double* __restrict__ c_r = colp + r2;       // col'_s[r2] at c_r[s * lda]
+  double nbv = -DBL_MAX;
+  int64_t nbi = -1;
+  for (int l = cb * kThreads + tid; l < ncl; l += n_cb * kThreads) {
+    const double t = chain_apply(T.col(l)[r2], j, c_r, sh.lda, rowp + l, rstride);
+    const double rp2 = __dmul_rn(t, f2);
+    double o = flushz(__dadd_rn(obj[l], __dmul_rn(t, g2)));   // :36
+    if (l == l_e2) o = 0.0;                                     // :37
+    obj[l] = o;
+    st_shared_f64(rowp + (int64_t)j * rstride + l, rp2);
+    if (l < sh.nloc) {
+      bool basic = is_basic[l] != 0;   // flags as before the pass, then the steps set up so far
+#pragma unroll 1
+      for (int s = 0; s < j; s++) {
+        const int in_s = __builtin_amdgcn_readlane(q_in, s), out_s = __builtin_amdgcn_readlane(q_out, s);
+        if (l == in_s) basic = true; else if (l == out_s) basic = false;
+      }
+      if (l == l_e2) basic = true; else if (l == l_d2) basic = false;
+      if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
+    }
+  }
+  wait_stores();                          // row'_j is out before this workgroup's record
+  block_arg<true, kThreads>(nbv, nbi, s_v, s_i);
+  __shared__ int64_t s_iter;
+  if (tid == 0) { next_pv[cb] = nbv; next_pi[cb] = nbi; s_iter = cb == 0 ? st->iter + 1 : 0; }
+  __syncthreads();
+  const int64_t iter_after = s_iter;
+  if (my_slot && tid < kFusedReplicas * kShardRecWords) {
+    // every thread holds the workgroup's result: thread c * kShardRecWords + x writes word x of copy c
+    const int x = tid % kShardRecWords;
+    const uint64_t vb = (uint64_t)__double_as_longlong(nbv);
+    const uint32_t word = x == 0 ? (uint32_t)vb : x == 1 ? (uint32_t)(vb >> 32) : x == 2 ? (uint32_t)(int32_t)nbi
+                        : x == 3 ? (uint32_t)(uint64_t)iter_after : (uint32_t)((uint64_t)iter_after >> 32);
+    rec_put(rec + (int64_t)(tid / kShardRecWords) * region + (int64_t)cb * kShardRecWords + x, word, tag);
+  }
+  if (keeper) {
+    ChainStep z;
+    z.done = 1; z.slot = 0; z.l_in = l_e2; z.l_out = l_d2;
+    z.e = e2; z.r = r2; z.d = d2; z.a = a2; z.ce = ce2; z.f = f2; z.g = g2;
+    steps[j] = z;
+    const int64_t it = iter_after - 1;
+    if (it < trace_cap) { trace[2 * it] = e2; trace[2 * it + 1] = r2; }
+    st->iter = iter_after;
+  }
+}
+
+}  // namespace lpamd
