@@ -193,6 +193,7 @@ def main():
         os._exit(3)
 
     group = None
+    link = False
     rccl_ranks = 0
     if world == 1 and not force_sharded and not use_dist:
         eng = lp.TableauEngine(m, N)
@@ -203,20 +204,24 @@ def main():
     else:
         if use_dist:
             import threading
-            ids = [lp.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            watchdog = threading.Timer(JOIN_TIMEOUT_S, fail, ["rank %d did not get through ncclCommInitRank within %d s (another rank "
-                                                              "may have failed before it, or RCCL cannot reach its peers)" % (rank, JOIN_TIMEOUT_S)])
-            watchdog.daemon = True
-            watchdog.start()
-            try:
-                group = lp.ShardGroup.join(m, N, rank, world, ids[0])
-            except Exception as ex:
-                fail("rank %d could not create its shard or join the communicator: %s" % (rank, ex))
-            watchdog.cancel()
-            rccl_ranks = group.comm_ranks()
-            if rccl_ranks != world:
-                fail("the communicator holds %d ranks, WORLD_SIZE is %d" % (rccl_ranks, world))
+
+            def join():
+                ids = [lp.comm_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                watchdog = threading.Timer(JOIN_TIMEOUT_S, fail, ["rank %d did not get through ncclCommInitRank within %d s (another rank "
+                                                                  "may have failed before it, or RCCL cannot reach its peers)" % (rank, JOIN_TIMEOUT_S)])
+                watchdog.daemon = True
+                watchdog.start()
+                try:
+                    grp = lp.ShardGroup.join(m, N, rank, world, ids[0])
+                except Exception as ex:
+                    fail("rank %d could not create its shard or join the communicator: %s" % (rank, ex))
+                watchdog.cancel()
+                if grp.comm_ranks() != world:
+                    fail("the communicator holds %d ranks, WORLD_SIZE is %d" % (grp.comm_ranks(), world))
+                return grp
+
+            group = join()
         elif shard_of > 1:
             group = lp.ShardGroup(m, N, shard_of, devices=[local_rank] * shard_of, rehearse_rank0=True)
         else:
@@ -226,11 +231,37 @@ def main():
         eng = group.engine(0)
         run = lambda k: group.run_pivots(strat, k)
         depth = min(group.chain(), eng.loop_depth(strat))   # MAX_REDUCTION passes may be shorter than MAX_COST ones
-        exchange = "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library"
+        link = group.link_active()
+        exchange = ("steps 2.. of a pass: every rank stores its slot (record + candidate column + its ratio-test partials, tagged words) into the "
+                    "peers' receive buffers from inside the step's own launch, no collective; step 1 of a pass and the pass boundary: one "
+                    "RCCL all-gather each" if link else
+                    "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library")
 
     K, W = args.steps, args.warmup
     if not args.exact_steps:
         K, W = max(round_up(max(K, 1), depth), MIN_TIMED_PASSES * depth), round_up(W, depth)
+    link_fallback = None
+    if use_dist and link:
+        # The exchange inside the launches has a self-test behind it but no run on this machine yet: a few passes decide.  If any
+        # rank's do not come through, every rank forms a new group that keeps the collective for every step, and says so.
+        try:
+            res, done = run(2 * depth)
+            good = done == 2 * depth and res == lp.LIMIT
+            why = "result %d after %d pivots" % (res, done)
+        except Exception as ex:
+            good, why = False, str(ex)
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            link_fallback = "the exchange inside the launches failed its trial passes on some rank (rank %d: %s): RCCL all-gather per pivot instead" % (
+                rank, why if not good else "fine here")
+            group.close()
+            os.environ["LPAMD_SHARD_LINK"] = "0"
+            group = join()
+            group.fill_synthetic(n, args.seed)
+            eng = group.engine(0)
+            link = group.link_active()
+            exchange = "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library"
     res, done = run(W)
     assert done == W and res == lp.LIMIT, "warm-up ended early: result %d after %d pivots" % (res, done)
     sync_all()
@@ -264,6 +295,15 @@ def main():
         per_rank = [{"rank": k, "achieved_GBps": round(float(v[0]), 1), "frac": round(float(v[0]) / HBM_PEAK_GBS, 4),
                      "avg_launch_ms": round(float(v[1]), 5), "streamed_columns_per_launch": round(float(v[2]), 1)} for k, v in enumerate(every)]
         achieved = min(float(v[0]) for v in every)   # the line's figure is the slowest rank's kernel rate
+    replicas_agree = None
+    if use_dist:
+        # every rank walks the same pivots on its replica of the state: a digest of each rank's trace says whether they did
+        import hashlib
+        digest = hashlib.sha256(repr(eng.trace()).encode()).digest()[:8]
+        mine_d = torch.tensor([int.from_bytes(digest, "little") >> 1], dtype=torch.int64, device=dev)
+        all_d = [torch.zeros_like(mine_d) for _ in range(world)]
+        dist.all_gather(all_d, mine_d)
+        replicas_agree = all(int(v.item()) == int(all_d[0].item()) for v in all_d)
     chained = passes > 0 and pivots > passes
     ratio, ratio_src = pmc_traffic_ratio(args.config, world, chained, args.strategy)
     per_launch = streamed_bytes / max(passes, 1)
@@ -285,7 +325,10 @@ def main():
         "data": "synthetic",
         "config": {"workload": args.config, "m": m, "n": n, "stored_columns": N + 1, "strategy": args.strategy,
                    "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world,
-                   "exchange": exchange, "pivots_per_pass": depth, "rccl_ranks": rccl_ranks,
+                   "exchange": exchange, "exchange_in_launch": bool(group is not None and link),
+                   **({"exchange_fallback": link_fallback} if link_fallback else {}),
+                   **({"replicas_walked_the_same_pivots": replicas_agree} if replicas_agree is not None else {}),
+                   "pivots_per_pass": depth, "rccl_ranks": rccl_ranks,
                    **({"rehearsal": "rank 0 of a %d-GPU run alone on one GPU" % shard_of} if shard_of > 1 else {})},
         "update_GBps_per_gpu": round(achieved, 1),
         "update_GBps_aggregate": round(achieved * world, 1),

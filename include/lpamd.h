@@ -278,6 +278,12 @@ int lpamd_group_shards(const lpamd_group* g, int32_t* n_local, int32_t* world);
 /* ranks the RCCL communicator of the first local shard really holds (ncclCommCount; 0 with the in-process exchange):
  * what a multi-GPU run reports so that a mis-formed communicator is seen, not inferred */
 int lpamd_group_comm_ranks(lpamd_group* g, int32_t* ranks);
+/* 1 when steps 2.. of a MAX_COST chain trade their slots INSIDE the step's launch (stores into the peers' receive buffers
+ * over xGMI, tagged words, no collective; only step 1 of a pass and the pass boundary keep the all-gather), 0 when every
+ * step runs the all-gather.  Decided when the group is formed: the ranks map each other's buffers (peer access inside one
+ * process, IPC handles traded through the communicator otherwise), run a self-test and agree on the outcome;
+ * LPAMD_SHARD_LINK=0 keeps the collective.  No counterpart in the reference (its tableau lives in one address space). */
+int lpamd_group_link_active(lpamd_group* g, int32_t* active);
 int lpamd_group_engine(lpamd_group* g, int32_t local_index, lpamd_engine** out);
 /* pivots one pass over a shard sets up at most in the MAX_COST loop (LPAMD_SHARD_CHAIN overrides) */
 int lpamd_group_chain(lpamd_group* g, int32_t* pivots_per_pass);

@@ -1087,6 +1087,19 @@ int64_t lpamd_exchange_bytes(int64_t m) { return round_up(std::max<int64_t>(m, 1
 
 static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int32_t rank, int32_t world, void* hip_stream);
 
+// Working buffer of an engine: allocated and CLEARED.  hipMalloc hands out whatever an earlier owner left (a freed array of
+// pointers reads as doubles of 1e-310 or 1e300), and a kernel that reads an entry before the first launch that writes it
+// must see the same bits in every run; zero is what fresh device memory holds and what every parity test ran on.
+// LPAMD_POISON=<field name>|all fills the named buffer with bytes of 0x7F instead (huge doubles and indices): a test that
+// changes its outcome under it reads that buffer before anything writes it.
+static int dev_alloc(lpamd_engine* e, void** out, size_t bytes, const char* name) {
+  HIP_TRY(hipMalloc(out, bytes));
+  const char* poison = getenv("LPAMD_POISON");
+  const int fill = (poison && (!strcmp(poison, "all") || !strcmp(poison, name))) ? 0x7F : 0;
+  HIP_TRY(hipMemsetAsync(*out, fill, bytes, e->stream));
+  return LPAMD_OK;
+}
+
 int lpamd_create(lpamd_engine** out, int64_t m, int64_t N, int32_t rank, int32_t world, void* hip_stream) {
   if (!out) return set_err(LPAMD_E_ARG, "out is null");
   *out = nullptr;
@@ -1152,7 +1165,10 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // against 2600 at 16), 23 steps 5.9 .. 6.1 ms (0.70 .. 0.73 from one machine to the next), 32 steps 7.5 ms (0.57 of
   // the peak, 3800 pivots/s).  The default is the deepest chain that keeps the pass clear of 0.70 of the peak on
   // every machine seen.  Shards that fit the Infinity Cache are bound by the set-up launches and stay at 16.
-  const bool hbm_sized = (double)e->sh.lda * (double)e->ncl * sizeof(double) > 512e6;
+  // Every rank of a deal must take the same depth (a step is a collective), so the size that decides it is that of the
+  // LARGEST shard of the deal (rank 0's), not this rank's own: shards differ by one column when N + 1 is no multiple of the world.
+  const double deal_bytes = (double)e->sh.lda * (double)((N + 1 + world - 1) / world + 1) * sizeof(double);
+  const bool hbm_sized = deal_bytes > 512e6;
   // Column shards of that size chain 26: their steps carry the export and the exchange on top of the set-up (20 us per step
   // beside 34 us of pass per pivot on a shard of 8), so the depth that pays is greater than on one GPU (rank 0 of 8: 18.7 k
   // pivots/s at 22, 19.7 k at 26, 19.8 k at 28 and 32; of 2: 6.35 k, 6.78 k, 6.95 k), at 0.67 of the HBM peak per rank.
@@ -1174,7 +1190,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // column shards: a MAX_REDUCTION step's cost grows with its position in the pass (six launches that each walk the steps so
   // far); on a 3 GB shard, where the set-up outweighs the pass, 22 per pass measured faster than 26 (rank 0 of 8 of m=32768
   // n=65536: 10.9 k against 10.0 k pivots/s), on a 21 GB shard slower (rank 0 of 8 of m=65536 n=262144: 2.70 k against 2.95 k)
-  if (world > 1 && hbm_sized && !getenv("LPAMD_CHAIN") && (double)e->sh.lda * (double)e->ncl * sizeof(double) < 8e9)
+  if (world > 1 && hbm_sized && !getenv("LPAMD_CHAIN") && deal_bytes < 8e9)
     e->mr_depth = std::min(e->chain_depth, 22);
   if (const char* env = getenv("LPAMD_MR_CHAIN")) { if (e->chain_depth > 1) e->mr_depth = std::max(2, std::min(kMaxChain, atoi(env))); }
   e->alloc_depth = std::max(e->chain_depth, e->mr_depth);
@@ -1204,46 +1220,46 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     e->own_stream = true;
   }
   LP_TRY(allocate_tableau(e));
-  HIP_TRY(hipMalloc(&e->obj, sizeof(double) * e->ncl));
-  HIP_TRY(hipMalloc(&e->is_basic, e->ncl));
-  HIP_TRY(hipMalloc(&e->basis, sizeof(int64_t) * m));
+  LP_TRY(dev_alloc(e, (void**)&e->obj, sizeof(double) * e->ncl, "obj"));
+  LP_TRY(dev_alloc(e, (void**)&e->is_basic, e->ncl, "is_basic"));
+  LP_TRY(dev_alloc(e, (void**)&e->basis, sizeof(int64_t) * m, "basis"));
   e->rstride = std::max<int64_t>(e->ncl, e->sh.lda);
-  HIP_TRY(hipMalloc(&e->colp, sizeof(double) * e->sh.lda * e->alloc_depth));
-  HIP_TRY(hipMalloc(&e->rowp, sizeof(double) * e->rstride * e->alloc_depth));
-  HIP_TRY(hipMalloc(&e->active, sizeof(int32_t) * e->ncl));
-  HIP_TRY(hipMalloc(&e->cmin, sizeof(double) * e->ncl));
-  HIP_TRY(hipMalloc(&e->crow, sizeof(int64_t) * e->ncl));
-  HIP_TRY(hipMalloc(&e->pr_stamp, sizeof(int64_t) * e->ncl));
-  HIP_TRY(hipMalloc(&e->rhs_next, sizeof(double) * e->sh.lda * e->alloc_depth));
-  HIP_TRY(hipMalloc(&e->cand_next, e->ncl));
+  LP_TRY(dev_alloc(e, (void**)&e->colp, sizeof(double) * e->sh.lda * e->alloc_depth, "colp"));
+  LP_TRY(dev_alloc(e, (void**)&e->rowp, sizeof(double) * e->rstride * e->alloc_depth, "rowp"));
+  LP_TRY(dev_alloc(e, (void**)&e->active, sizeof(int32_t) * e->ncl, "active"));
+  LP_TRY(dev_alloc(e, (void**)&e->cmin, sizeof(double) * e->ncl, "cmin"));
+  LP_TRY(dev_alloc(e, (void**)&e->crow, sizeof(int64_t) * e->ncl, "crow"));
+  LP_TRY(dev_alloc(e, (void**)&e->pr_stamp, sizeof(int64_t) * e->ncl, "pr_stamp"));
+  LP_TRY(dev_alloc(e, (void**)&e->rhs_next, sizeof(double) * e->sh.lda * e->alloc_depth, "rhs_next"));
+  LP_TRY(dev_alloc(e, (void**)&e->cand_next, e->ncl, "cand_next"));
   HIP_TRY(hipMemsetAsync(e->pr_stamp, 0xFF, sizeof(int64_t) * e->ncl, e->stream));
   HIP_TRY(hipMemsetAsync(e->rhs_next, 0, sizeof(double) * e->sh.lda * e->alloc_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->cand_next, 0, e->ncl, e->stream));
-  HIP_TRY(hipMalloc(&e->steps, sizeof(ChainStep) * kMaxChain));
+  LP_TRY(dev_alloc(e, (void**)&e->steps, sizeof(ChainStep) * kMaxChain, "steps"));
   HIP_TRY(hipMemsetAsync(e->steps, 0, sizeof(ChainStep) * kMaxChain, e->stream));
-  HIP_TRY(hipMalloc(&e->colv, sizeof(double) * 2 * e->sh.lda));   // k_chain_fused keeps two copies that take turns
+  LP_TRY(dev_alloc(e, (void**)&e->colv, sizeof(double) * 2 * e->sh.lda, "colv"));   // k_chain_fused keeps two copies that take turns
   // MAX_REDUCTION prices from bounds wherever pivots chain
   e->pr_bounds = e->chain_depth > 1;
   if (const char* env = getenv("LPAMD_PR_BOUNDS")) e->pr_bounds = e->pr_bounds && atoi(env) != 0;
   if (e->pr_bounds) {
-    HIP_TRY(hipMalloc(&e->prb_info, sizeof(PrbInfo)));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_info, sizeof(PrbInfo), "prb_info"));
     HIP_TRY(hipMemsetAsync(e->prb_info, 0, sizeof(PrbInfo), e->stream));
-    HIP_TRY(hipMalloc(&e->prb_c, sizeof(double) * kMaxChain * kPrbRows));
-    HIP_TRY(hipMalloc(&e->prb_cache, sizeof(double) * kPrbRows * (size_t)std::max<int64_t>(1, e->sh.nloc)));
-    HIP_TRY(hipMalloc(&e->prb_v, sizeof(double) * 3 * kMaxPartials));
-    HIP_TRY(hipMalloc(&e->prb_i, sizeof(int64_t) * 3 * kMaxPartials));
-    HIP_TRY(hipMalloc(&e->prb_ep_v, sizeof(double) * kPrbSliced * kPrbSlices));
-    HIP_TRY(hipMalloc(&e->prb_ep_i, sizeof(int64_t) * kPrbSliced * kPrbSlices));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_c, sizeof(double) * kMaxChain * kPrbRows, "prb_c"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_cache, sizeof(double) * kPrbRows * (size_t)std::max<int64_t>(1, e->sh.nloc), "prb_cache"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_v, sizeof(double) * 3 * kMaxPartials, "prb_v"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_i, sizeof(int64_t) * 3 * kMaxPartials, "prb_i"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_ep_v, sizeof(double) * kPrbSliced * kPrbSlices, "prb_ep_v"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_ep_i, sizeof(int64_t) * kPrbSliced * kPrbSlices, "prb_ep_i"));
     if (const char* env = getenv("LPAMD_PRB_ROWS")) e->prb_rows = std::max(1, std::min(kPrbRows, atoi(env)));
     if (const char* env = getenv("LPAMD_PRB_CACHE")) e->prb_use_cache = atoi(env) != 0;
     if (const char* env = getenv("LPAMD_PRB_RENEW")) e->prb_renew = std::max(1, atoi(env));
     if (const char* env = getenv("LPAMD_PRB_CARRY")) e->prb_carry = atoi(env) != 0;
     if (const char* env = getenv("LPAMD_PRB_BOUND_BLOCKS")) e->prb_bound_blocks = std::max(0, atoi(env));
-    HIP_TRY(hipMalloc(&e->prb_ub, sizeof(double) * e->ncl));
-    HIP_TRY(hipMalloc(&e->prb_ucand, e->ncl));
-    HIP_TRY(hipMalloc(&e->prb_elist, sizeof(int32_t) * e->ncl));
-    HIP_TRY(hipMalloc(&e->prb_escore, sizeof(double) * e->ncl));
-    HIP_TRY(hipMalloc(&e->prb_erow, sizeof(int64_t) * e->ncl));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_ub, sizeof(double) * e->ncl, "prb_ub"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_ucand, e->ncl, "prb_ucand"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_elist, sizeof(int32_t) * e->ncl, "prb_elist"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_escore, sizeof(double) * e->ncl, "prb_escore"));
+    LP_TRY(dev_alloc(e, (void**)&e->prb_erow, sizeof(int64_t) * e->ncl, "prb_erow"));
     // k_prb_tail: every workgroup of its grid must be resident at the same time (they wait for each other's records); the
     // grid may take three quarters of what the device holds of the kernel, and 512 workgroups at most (record polls)
     e->prb_tail = world == 1;
@@ -1262,9 +1278,9 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     if (e->prb_tail) {
       const int grid = e->tail_rows + e->tail_cols;
       const size_t words = (size_t)kFusedReplicas * (fused_region_words(grid, kTailEvalWords) + fused_region_words(grid, kTailBackWords));
-      HIP_TRY(hipMalloc(&e->prb_top_u, sizeof(double) * 2 * kMaxPartials));
-      HIP_TRY(hipMalloc(&e->prb_top_l, sizeof(int32_t) * kMaxPartials));
-      HIP_TRY(hipMalloc(&e->rec_tail, sizeof(uint64_t) * words));
+      LP_TRY(dev_alloc(e, (void**)&e->prb_top_u, sizeof(double) * 2 * kMaxPartials, "prb_top_u"));
+      LP_TRY(dev_alloc(e, (void**)&e->prb_top_l, sizeof(int32_t) * kMaxPartials, "prb_top_l"));
+      LP_TRY(dev_alloc(e, (void**)&e->rec_tail, sizeof(uint64_t) * words, "rec_tail"));
       HIP_TRY(hipMemsetAsync(e->rec_tail, 0, sizeof(uint64_t) * words, e->stream));
     }
   }
@@ -1308,26 +1324,26 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     if (blocks(e->ncl, (int64_t)e->fused_cols * threads) > 32) e->fused = false;
   }
   if (e->fused) {
-    HIP_TRY(hipMalloc(&e->rec_ratio, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_rows, kFusedRatioWords)));
-    HIP_TRY(hipMalloc(&e->rec_price, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_cols, kFusedPriceWords)));
+    LP_TRY(dev_alloc(e, (void**)&e->rec_ratio, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_rows, kFusedRatioWords), "rec_ratio"));
+    LP_TRY(dev_alloc(e, (void**)&e->rec_price, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_cols, kFusedPriceWords), "rec_price"));
     HIP_TRY(hipMemsetAsync(e->rec_ratio, 0, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_rows, kFusedRatioWords), e->stream));
     HIP_TRY(hipMemsetAsync(e->rec_price, 0, sizeof(uint64_t) * 2 * kFusedReplicas * fused_region_words(e->fused_cols, kFusedPriceWords), e->stream));
   }
-  HIP_TRY(hipMalloc(&e->pass, sizeof(PassInfo)));
+  LP_TRY(dev_alloc(e, (void**)&e->pass, sizeof(PassInfo), "pass"));
   HIP_TRY(hipMemsetAsync(e->pass, 0, sizeof(PassInfo), e->stream));
   if (e->chain_depth > 1) {
-    HIP_TRY(hipMalloc(&e->list_full, sizeof(int32_t) * e->ncl));
-    HIP_TRY(hipMalloc(&e->list_part, sizeof(int32_t) * e->ncl));
-    HIP_TRY(hipMalloc(&e->rsl_full, sizeof(double) * (size_t)(e->ncl + 8) * e->alloc_depth));   // whole batches of up to 8 columns
-    HIP_TRY(hipMalloc(&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->alloc_depth));
-    HIP_TRY(hipMalloc(&e->ptr_full, sizeof(uint64_t) * (size_t)(e->ncl + 8)));
+    LP_TRY(dev_alloc(e, (void**)&e->list_full, sizeof(int32_t) * e->ncl, "list_full"));
+    LP_TRY(dev_alloc(e, (void**)&e->list_part, sizeof(int32_t) * e->ncl, "list_part"));
+    LP_TRY(dev_alloc(e, (void**)&e->rsl_full, sizeof(double) * (size_t)(e->ncl + 8) * e->alloc_depth, "rsl_full"));   // whole batches of up to 8 columns
+    LP_TRY(dev_alloc(e, (void**)&e->rsl_part, sizeof(double) * (size_t)e->ncl * e->alloc_depth, "rsl_part"));
+    LP_TRY(dev_alloc(e, (void**)&e->ptr_full, sizeof(uint64_t) * (size_t)(e->ncl + 8), "ptr_full"));
   }
   HIP_TRY(hipMemsetAsync(e->colv, 0, sizeof(double) * 2 * e->sh.lda, e->stream));    // rows beyond m stay zero
-  HIP_TRY(hipMalloc(&e->cand, sizeof(Candidate)));
-  HIP_TRY(hipMalloc(&e->cand_la, sizeof(Candidate)));
+  LP_TRY(dev_alloc(e, (void**)&e->cand, sizeof(Candidate), "cand"));
+  LP_TRY(dev_alloc(e, (void**)&e->cand_la, sizeof(Candidate), "cand_la"));
   HIP_TRY(hipMemsetAsync(e->cand_la, 0xFF, sizeof(Candidate), e->stream));   // gcol = -1: no candidate
-  HIP_TRY(hipMalloc(&e->part_v, sizeof(double) * 2 * kMaxPartials));
-  HIP_TRY(hipMalloc(&e->part_i, sizeof(int64_t) * 3 * kMaxPartials));
+  LP_TRY(dev_alloc(e, (void**)&e->part_v, sizeof(double) * 2 * kMaxPartials, "part_v"));
+  LP_TRY(dev_alloc(e, (void**)&e->part_i, sizeof(int64_t) * 3 * kMaxPartials, "part_i"));
   // partial reductions: 256 columns / 256 rows per workgroup, strided beyond kMaxPartials workgroups
   e->n_price_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (nloc + 1 + kPartialThreads - 1) / kPartialThreads));
   e->n_ratio_part = (int32_t)std::min<int64_t>(kMaxPartials, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));
@@ -1339,16 +1355,16 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   if (const char* env = getenv("LPAMD_SHARD_STEP")) e->shard_step = e->shard_step && atoi(env) != 0;
   if (e->shard_step) {
     int per_cu = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shard_step, kPartialThreads, 0) != hipSuccess ||
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shard_step<true, true>, kPartialThreads, 0) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
     if ((int64_t)(e->n_row_blocks + e->n_price_part) * 4 > (int64_t)per_cu * cus * 3) e->shard_step = false;
   }
   if (e->shard_step) {
     const size_t words = (size_t)kFusedReplicas * fused_region_words(e->n_price_part, kShardRecWords);
-    HIP_TRY(hipMalloc(&e->rec_shard, sizeof(uint64_t) * words));
+    LP_TRY(dev_alloc(e, (void**)&e->rec_shard, sizeof(uint64_t) * words, "rec_shard"));
     HIP_TRY(hipMemsetAsync(e->rec_shard, 0, sizeof(uint64_t) * words, e->stream));
   }
-  HIP_TRY(hipMalloc(&e->st, sizeof(PivotState)));
+  LP_TRY(dev_alloc(e, (void**)&e->st, sizeof(PivotState), "st"));
   HIP_TRY(hipMemsetAsync(e->colp, 0, sizeof(double) * e->sh.lda * e->alloc_depth, e->stream));
   HIP_TRY(hipMemsetAsync(e->st, 0, sizeof(PivotState), e->stream));
   std::memset(&e->h_st, 0, sizeof(PivotState));
@@ -2137,10 +2153,17 @@ int export_lookahead_ratio(lpamd_engine* e, uint64_t* slot, int header_words) {
 }
 
 // The two together: set-up of step `pending_steps` from the gathered slots and, into `next_slot` (nullptr: none), this rank's
-// slot for the step after it (k_shard_step).  False in *done when the engine cannot run it (see lpamd_create).
-int chain_step_export_from_slots(lpamd_engine* e, const uint64_t* slots, int world, int64_t slot_words, int header_words, uint64_t* next_slot) {
+// slot for the step after it (k_shard_step).  link (nullptr: none): the exchange inside the launch; tag_in != 0: the slots
+// are read from this rank's receive buffer, tag_out != 0: the slot goes straight into every rank's receive buffer.
+int chain_step_export_from_slots(lpamd_engine* e, const uint64_t* slots, int world, int64_t slot_words, int header_words, uint64_t* next_slot,
+                                 const ShardLink* link = nullptr) {
   if (!e->update_pending) return set_err(LPAMD_E_STATE, "chain step: no pivot has been set up by lpamd_lookahead_setup");
   if (e->pending_steps >= e->chain_depth) return set_err(LPAMD_E_STATE, "chain step: the pass already holds %d pivots", e->pending_steps);
+  ShardLink lk{};
+  if (link) lk = *link;
+  const bool in = lk.tag_in != 0, out = lk.tag_out != 0;
+  if ((in || out) && (world > kWave || !lk.peers || !lk.in)) return set_err(LPAMD_E_ARG, "chain step: bad link");
+  if (out && !next_slot) return set_err(LPAMD_E_ARG, "chain step: a slot is exported only when a next step follows");
   e->apply_since_pull++;
   LP_TRY(ensure_trace(e, e->h_st.iter + e->apply_since_pull + 2));
   e->shard_epoch = (e->shard_epoch + 1) & 0xFFFFFFu;
@@ -2148,10 +2171,11 @@ int chain_step_export_from_slots(lpamd_engine* e, const uint64_t* slots, int wor
     HIP_TRY(hipMemsetAsync(e->rec_shard, 0, sizeof(uint64_t) * (size_t)kFusedReplicas * fused_region_words(e->n_price_part, kShardRecWords), e->stream));
     e->shard_epoch = 1;
   }
-  hipLaunchKernelGGL(k_shard_step, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps,
+  auto kernel = in ? (out ? k_shard_step<true, true> : k_shard_step<true, false>) : (out ? k_shard_step<false, true> : k_shard_step<false, false>);
+  hipLaunchKernelGGL(kernel, dim3(e->n_row_blocks + e->n_price_part), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps,
                      e->pending_steps, (int)slot_ratio_parts(e), e->n_row_blocks, e->colp, e->rowp, e->rstride, e->rhs_next, e->obj, e->is_basic,
                      e->basis, e->trace, e->trace_cap, e->part_v, e->part_i, slots, world, slot_words, header_words, e->chain_depth, next_slot,
-                     e->rec_shard, e->shard_epoch);
+                     e->rec_shard, e->shard_epoch, lk);
   LP_TRY(check_launch("k_shard_step"));
   e->price_partials_fresh = true;
   e->pending_steps++;

@@ -111,6 +111,21 @@ __global__ __launch_bounds__(256) void k_sum_words(const uint64_t* __restrict__ 
   out[i] = s;
 }
 
+// Self-test of the in-launch exchange (ShardLink) when a group is formed: every rank stores a tagged token into every
+// rank's hello words, then looks for every rank's token in its own.
+__global__ __launch_bounds__(kWave) void k_link_hello_put(uint64_t* const* __restrict__ peers, int world, int64_t hello_at, int my_rank) {
+  if ((int)threadIdx.x < world) ll_put(peers[threadIdx.x] + hello_at + 2 * my_rank, 0xC0FFEE00ull + (uint64_t)my_rank, 1u);
+}
+__global__ __launch_bounds__(kWave) void k_link_hello_get(const uint64_t* __restrict__ in, int world, int64_t hello_at, int32_t* __restrict__ ok) {
+  bool good = true;
+  if ((int)threadIdx.x < world) {
+    uint64_t v = 0;
+    good = ll_get(in + hello_at + 2 * threadIdx.x, 1u, v, 2LL * 100000000LL) && v == 0xC0FFEE00ull + (uint64_t)threadIdx.x;
+  }
+  const unsigned long long bad = __ballot(!good);
+  if (threadIdx.x == 0) *ok = bad == 0 ? 1 : 0;
+}
+
 }  // namespace lpamd
 
 namespace {
@@ -213,6 +228,12 @@ struct lpamd_shard {   // one column shard of a group and its exchange state
   uint64_t* send = nullptr;                  // assembly of rows / columns / objective: max(N + 2, lda) words ...
   uint64_t* stage = nullptr;                 // ... world blocks of them ...
   uint64_t* summed = nullptr;                // ... and their exact sum
+  // exchange inside the chained step's launch (ShardLink, lpamd_shardstep_kernels.hip.h)
+  uint64_t* link_buf = nullptr;              // kLinkBuffers x world slots of tagged words, then the hello words: what the ranks store into
+  uint64_t** link_peers = nullptr;           // device array [world]: every rank's link_buf as this process maps it
+  int32_t* link_ok = nullptr;                // result of the self-test
+  std::vector<void*> link_mapped;            // peers' buffers opened through IPC handles
+  uint32_t link_tag = 0;                     // tag of the last slot exported that way
   int rc = LPAMD_OK;
   std::string err;
 };
@@ -224,6 +245,8 @@ struct lpamd_group {
   bool local_exchange = false;
   bool inline_exchange = true;    // collectives inside a chain run on the engine's stream (nothing to overlap them with)
   bool fused_step = true;         // MAX_COST steps inside a chain: ratio-test partials travel with the slot, two launches per step
+  bool link = false;              // MAX_COST steps 2.. of a chain: the slots travel inside the step's launch, no collective
+  int64_t ll_words = 0;           // tagged words per slot
   int chain = 1;                  // pivots per pass of the look-ahead loop
   int chain_mr = 1;               // ... and of the MAX_REDUCTION loop
   int poll_every = 64;
@@ -317,6 +340,20 @@ int all_gather_words(Group* g, Shard& s, const uint64_t* send, uint64_t* recv, i
   return LPAMD_OK;
 }
 
+// Shards of one process that share a GPU and trade inside their launches (ShardLink): a launch that waits for another
+// shard's launch must not sit in front of it in a hardware queue the two streams happen to share (the runtime deals its
+// streams over a few queues, and a queue starts its packets in order), so every shard's stream first waits for what the
+// other shards have enqueued so far.  The slots still travel by the launches' own stores and are read by polling.
+int link_fence_local(Group* g, Shard& s, hipStream_t stream) {
+  if (!g->local_exchange || g->shards.size() < 2) return LPAMD_OK;
+  HIP_TRY(hipEventRecord(s.ev_pub, stream));
+  if (!g->barrier.wait()) return set_err(LPAMD_E_STATE, "another shard failed");
+  for (Shard& q : g->shards)
+    if (&q != &s) HIP_TRY(hipStreamWaitEvent(stream, q.ev_pub, 0));
+  if (!g->barrier.wait()) return set_err(LPAMD_E_STATE, "another shard failed");
+  return LPAMD_OK;
+}
+
 // Every rank gets the element-wise exact sum of the ranks' host vectors (n doubles; at most
 // one rank contributes a non-zero bit pattern per entry).  Synchronises.
 int sum_exact(Group* g, Shard& s, double* vec, int64_t n) {
@@ -399,6 +436,24 @@ int export_lookahead(Shard& s) {
   return lpamd_lookahead_export(s.eng, s.slot, s.slot + kSlotHeaderWords);
 }
 
+// With the exchange inside the launches a rank can end up in ST_ERROR alone (a slot that did not arrive in time), and the
+// ranks would then leave the loop at different reads of the state, one of them with collectives enqueued that the other
+// never joins.  So the ranks of a communicator trade what they have read and all stop as soon as one has stopped.
+int agree_on_result(Group* g, Shard& s, int32_t* res) {
+  if (!g->link || g->local_exchange) return LPAMD_OK;   // (a world of one trades with itself: the rehearsal walks this code)
+  hipStream_t st = s.eng->stream;
+  const uint64_t mine = (uint64_t)(uint32_t)*res;
+  std::vector<uint64_t> every(g->world, 0);
+  HIP_TRY(hipStreamWaitEvent(st, s.ev_arrived, 0));   // one collective of a communicator at a time: the exchange for the next pass first
+  HIP_TRY(hipMemcpyAsync(s.send, &mine, sizeof(mine), hipMemcpyHostToDevice, st));
+  LP_TRY(all_gather_words(g, s, s.send, s.stage, 1, st));
+  HIP_TRY(hipMemcpyAsync(every.data(), s.stage, sizeof(uint64_t) * g->world, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  for (int k = 0; k < g->world; k++)
+    if ((int32_t)every[k] != *res && *res == LPAMD_LIMIT) *res = (int32_t)every[k] == LPAMD_LIMIT ? *res : LPAMD_ERROR;
+  return LPAMD_OK;
+}
+
 // MAX_COST: look-ahead exchange and chains of pivots per pass (see lpamd.h, lpamd_lookahead_* and
 // lpamd_chain_step).  Per pass: set-up of the first pivot on the column the previous exchange
 // delivered; chain - 1 times {export with ratio-test partials, all-gather, set-up straight from the
@@ -421,11 +476,24 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
       HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));
       LP_TRY(lpamd_lookahead_setup(e, s.xbuf));
       if (g->fused_step && e->shard_step && g->chain > 1) {
-        // one launch and the collective per step: the set-up of step j also leaves this rank's slot for step j+1
+        // one launch and the collective per step: the set-up of step j also leaves this rank's slot for step j+1.
+        // With the link, only step 1's slots travel by the collective: from then on the launch stores the slot into every
+        // rank's receive buffer and the next launch reads it there (tags: see ShardLink).
         LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));
         for (int j = 1; j < g->chain; j++) {
-          LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
-          LP_TRY(chain_step_export_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords, j + 1 < g->chain ? s.slot : nullptr));
+          const bool last = j + 1 >= g->chain;
+          if (!g->link || j == 1) LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
+          else LP_TRY(link_fence_local(g, s, e->stream));
+          ShardLink lk{};
+          if (g->link) {
+            lk.peers = s.link_peers;
+            lk.in = s.link_buf;
+            lk.ll_words = g->ll_words;
+            lk.my_rank = s.rank;
+            lk.tag_in = j > 1 ? s.link_tag : 0;
+            if (!last) { s.link_tag = s.link_tag + 1 == 0 ? 1 : s.link_tag + 1; lk.tag_out = s.link_tag; }
+          }
+          LP_TRY(chain_step_export_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords, last ? nullptr : s.slot, g->link ? &lk : nullptr));
         }
       } else
       for (int j = 1; j < g->chain; j++) {
@@ -446,6 +514,7 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
     }
     enqueued += passes * g->chain;
     LP_TRY(lpamd_poll(e, &res));
+    LP_TRY(agree_on_result(g, s, &res));
     if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
   }
   HIP_TRY(hipStreamWaitEvent(e->stream, s.ev_arrived, 0));   // the last exchange is not consumed; keep the streams ordered
@@ -683,6 +752,46 @@ int solve_shard(Group* g, Shard& s, int32_t strategy, int64_t max_pivots, int32_
   return lpamd_pivot_count(e, n_pivots);
 }
 
+// Receive buffers of the exchange inside a launch: memory that no cache of this or another GPU keeps a copy of (the peers
+// store into it, this rank polls it).  Such memory is kept for the life of the PROCESS and handed from group to group
+// (cleared each time), never given back to the allocator: pages that were mapped uncached, freed and handed out again by
+// hipMalloc as ordinary memory were seen to serve OLD contents to the kernels of the next owner (the second of two groups
+// created one after the other walked other pivots from its third pivot on; with the buffers from hipMalloc, or kept, it
+// does not).  A process holds as many of them as it had shards alive at once, a few MB each.
+struct LinkBlock { int device; size_t bytes; uint64_t* ptr; bool in_use; };
+std::mutex g_link_pool_mutex;
+std::vector<LinkBlock> g_link_pool;
+
+int link_pool_get(int device, size_t bytes, uint64_t** out) {
+  std::lock_guard<std::mutex> lock(g_link_pool_mutex);
+  LinkBlock* hit = nullptr;
+  for (LinkBlock& b : g_link_pool)
+    if (!b.in_use && b.device == device && b.bytes == bytes) { hit = &b; break; }
+  if (!hit) {
+    uint64_t* p = nullptr;
+    const char* dbg_mem = getenv("LPAMD_LINK_MEM");   // experiments only: "plain" takes hipMalloc memory
+    if (dbg_mem && !strcmp(dbg_mem, "plain")) HIP_TRY(hipMalloc(&p, bytes));
+    else if (hipExtMallocWithFlags((void**)&p, bytes, hipDeviceMallocUncached) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      HIP_TRY(hipExtMallocWithFlags((void**)&p, bytes, hipDeviceMallocFinegrained));
+    }
+    g_link_pool.push_back(LinkBlock{device, bytes, p, false});
+    hit = &g_link_pool.back();
+  }
+  HIP_TRY(hipMemset(hit->ptr, 0, bytes));    // tags of an earlier group must not read as this one's
+  HIP_TRY(hipDeviceSynchronize());
+  hit->in_use = true;
+  *out = hit->ptr;
+  return LPAMD_OK;
+}
+void link_pool_put(uint64_t* p) {
+  if (!p) return;
+  std::lock_guard<std::mutex> lock(g_link_pool_mutex);
+  for (LinkBlock& b : g_link_pool)
+    if (b.ptr == p) b.in_use = false;
+}
+
 void destroy_shard(Group* g, Shard& s) {
   (void)hipSetDevice(s.device);
   if (s.eng && s.eng->stream) (void)hipStreamSynchronize(s.eng->stream);   // (returns once an aborted collective has been flushed)
@@ -693,6 +802,10 @@ void destroy_shard(Group* g, Shard& s) {
   }
   for (hipEvent_t ev : {s.ev_sent, s.ev_arrived, s.ev_pub, s.ev_read})
     if (ev) (void)hipEventDestroy(ev);
+  for (void* p : s.link_mapped) (void)hipIpcCloseMemHandle(p);
+  link_pool_put(s.link_buf);
+  for (void* p : {(void*)s.link_peers, (void*)s.link_ok})
+    if (p) (void)hipFree(p);
   if (s.xstream) (void)hipStreamDestroy(s.xstream);
   for (void* p : {(void*)s.slot, (void*)s.slots, (void*)s.xbuf, (void*)s.send, (void*)s.stage, (void*)s.summed})
     if (p) (void)hipFree(p);
@@ -701,6 +814,9 @@ void destroy_shard(Group* g, Shard& s) {
   (void)g;
 }
 
+int64_t link_hello_at(const Group* g) { return (int64_t)kLinkBuffers * g->world * g->ll_words; }
+int64_t link_words(const Group* g) { return link_hello_at(g) + 2 * (int64_t)g->world + 64; }
+
 int init_shard(Group* g, Shard& s, int rank, int device) {
   s.rank = rank;
   s.device = device;
@@ -708,16 +824,120 @@ int init_shard(Group* g, Shard& s, int rank, int device) {
   LP_TRY(lpamd_create(&s.eng, g->m, g->N, rank, g->engine_world, nullptr));
   HIP_TRY(hipStreamCreateWithFlags(&s.xstream, hipStreamNonBlocking));
   for (hipEvent_t* ev : {&s.ev_sent, &s.ev_arrived, &s.ev_pub, &s.ev_read}) HIP_TRY(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-  HIP_TRY(hipMalloc(&s.slot, sizeof(uint64_t) * g->slot_words));
-  HIP_TRY(hipMalloc(&s.slots, sizeof(uint64_t) * g->slot_words * g->world));
-  HIP_TRY(hipMalloc(&s.xbuf, sizeof(double) * g->lda));
-  HIP_TRY(hipMalloc(&s.send, sizeof(uint64_t) * g->wide));
-  HIP_TRY(hipMalloc(&s.stage, sizeof(uint64_t) * g->wide * g->world));
-  HIP_TRY(hipMalloc(&s.summed, sizeof(uint64_t) * g->wide));
-  HIP_TRY(hipMemset(s.slot, 0, sizeof(uint64_t) * g->slot_words));
-  HIP_TRY(hipMemset(s.slots, 0, sizeof(uint64_t) * g->slot_words * g->world));
-  HIP_TRY(hipMemset(s.xbuf, 0, sizeof(double) * g->lda));
-  HIP_TRY(hipMemset(s.send, 0, sizeof(uint64_t) * g->wide));
+  LP_TRY(dev_alloc(s.eng, (void**)&s.slot, sizeof(uint64_t) * g->slot_words, "slot"));
+  LP_TRY(dev_alloc(s.eng, (void**)&s.slots, sizeof(uint64_t) * g->slot_words * g->world, "slots"));
+  LP_TRY(dev_alloc(s.eng, (void**)&s.xbuf, sizeof(double) * g->lda, "xbuf"));
+  LP_TRY(dev_alloc(s.eng, (void**)&s.send, sizeof(uint64_t) * g->wide, "send"));
+  LP_TRY(dev_alloc(s.eng, (void**)&s.stage, sizeof(uint64_t) * g->wide * g->world, "stage"));
+  LP_TRY(dev_alloc(s.eng, (void**)&s.summed, sizeof(uint64_t) * g->wide, "summed"));
+  HIP_TRY(hipStreamSynchronize(s.eng->stream));
+  if (g->link) {
+    LP_TRY(link_pool_get(device, sizeof(uint64_t) * (size_t)link_words(g), &s.link_buf));
+    HIP_TRY(hipMalloc(&s.link_peers, sizeof(uint64_t*) * g->world));
+    HIP_TRY(hipMalloc(&s.link_ok, sizeof(int32_t)));
+    HIP_TRY(hipMemset(s.link_ok, 0, sizeof(int32_t)));
+  }
+  return LPAMD_OK;
+}
+
+// ---- the exchange inside the launch: who maps whose receive buffers ---------------------------------
+// Shards of ONE process: plain pointers (peer access between the devices switched on), then the self-test.
+int link_connect_local(Group* g) {
+  if (!g->link) return LPAMD_OK;
+  for (Shard& s : g->shards) g->link = g->link && s.eng->shard_step;
+  if (g->chain < 3) g->link = false;       // nothing to carry: step 1's slots travel by the collective
+  if (!g->link) return LPAMD_OK;
+  std::vector<uint64_t*> peers(g->world, nullptr);
+  for (Shard& s : g->shards) peers[s.rank] = s.link_buf;
+  for (Shard& s : g->shards) {
+    HIP_TRY(hipSetDevice(s.device));
+    for (Shard& q : g->shards)
+      if (q.device != s.device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, s.device, q.device) != hipSuccess || !can) { (void)hipGetLastError(); g->link = false; return LPAMD_OK; }
+        const hipError_t err = hipDeviceEnablePeerAccess(q.device, 0);
+        if (err != hipSuccess && err != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); g->link = false; return LPAMD_OK; }
+        (void)hipGetLastError();
+      }
+    HIP_TRY(hipMemcpy(s.link_peers, peers.data(), sizeof(uint64_t*) * g->world, hipMemcpyHostToDevice));
+  }
+  if (getenv("LPAMD_LINK_NOHELLO")) return LPAMD_OK;   // experiments only
+  for (Shard& s : g->shards) {
+    HIP_TRY(hipSetDevice(s.device));
+    hipLaunchKernelGGL(k_link_hello_put, dim3(1), dim3(kWave), 0, s.eng->stream, s.link_peers, g->world, link_hello_at(g), s.rank);
+    LP_TRY(check_launch("k_link_hello_put"));
+  }
+  for (Shard& s : g->shards) { HIP_TRY(hipSetDevice(s.device)); HIP_TRY(hipStreamSynchronize(s.eng->stream)); }
+  bool all = true;
+  for (Shard& s : g->shards) {
+    HIP_TRY(hipSetDevice(s.device));
+    hipLaunchKernelGGL(k_link_hello_get, dim3(1), dim3(kWave), 0, s.eng->stream, s.link_buf, g->world, link_hello_at(g), s.link_ok);
+    LP_TRY(check_launch("k_link_hello_get"));
+    int32_t ok = 0;
+    HIP_TRY(hipMemcpyAsync(&ok, s.link_ok, sizeof(ok), hipMemcpyDeviceToHost, s.eng->stream));
+    HIP_TRY(hipStreamSynchronize(s.eng->stream));
+    all = all && ok == 1;
+  }
+  g->link = all;
+  return LPAMD_OK;
+}
+
+// One process per GPU: the ranks trade IPC handles of their receive buffers through the communicator, map each other's,
+// run the self-test and agree on its outcome; anything short of "every rank reached every rank" leaves the collective in
+// charge on ALL ranks.  Collective: every rank makes the same three all-gathers whatever happens to it locally.
+int link_connect_ranks(Group* g, Shard& s) {
+  if (!g->link) return LPAMD_OK;
+  hipStream_t st = s.eng->stream;
+  constexpr int kWords = 1 + (int)(sizeof(hipIpcMemHandle_t) / sizeof(uint64_t));
+  static_assert(sizeof(hipIpcMemHandle_t) % sizeof(uint64_t) == 0, "handles travel as 64-bit words");
+  std::vector<uint64_t> mine(kWords, 0), every((size_t)kWords * g->world, 0);
+  hipIpcMemHandle_t h;
+  // (g->link is what the environment asked for, the same on every rank; whether THIS rank's engine runs the one-launch
+  // step is not, and travels with the handle)
+  if (!s.eng->shard_step || g->chain < 3) mine[0] = 0;
+  else if (hipIpcGetMemHandle(&h, s.link_buf) == hipSuccess) { mine[0] = 1; std::memcpy(&mine[1], &h, sizeof(h)); }
+  else (void)hipGetLastError();
+  auto gather = [&](int words) -> int {
+    HIP_TRY(hipMemcpyAsync(s.send, mine.data(), sizeof(uint64_t) * words, hipMemcpyHostToDevice, st));
+    LP_TRY(all_gather_words(g, s, s.send, s.stage, words, st));
+    HIP_TRY(hipMemcpyAsync(every.data(), s.stage, sizeof(uint64_t) * words * g->world, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LPAMD_OK;
+  };
+  LP_TRY(gather(kWords));
+  bool good = true;
+  for (int k = 0; k < g->world; k++) good = good && every[(size_t)k * kWords] == 1;
+  std::vector<uint64_t*> peers(g->world, nullptr);
+  if (good) {
+    for (int k = 0; k < g->world && good; k++) {
+      if (k == s.rank) { peers[k] = s.link_buf; continue; }
+      hipIpcMemHandle_t hk;
+      std::memcpy(&hk, &every[(size_t)k * kWords + 1], sizeof(hk));
+      void* p = nullptr;
+      if (hipIpcOpenMemHandle(&p, hk, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); good = false; break; }
+      s.link_mapped.push_back(p);
+      peers[k] = static_cast<uint64_t*>(p);
+    }
+  }
+  if (good) {
+    HIP_TRY(hipMemcpyAsync(s.link_peers, peers.data(), sizeof(uint64_t*) * g->world, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_link_hello_put, dim3(1), dim3(kWave), 0, st, s.link_peers, g->world, link_hello_at(g), s.rank);
+    LP_TRY(check_launch("k_link_hello_put"));
+  }
+  mine[0] = good ? 1 : 0;
+  LP_TRY(gather(1));                       // also a barrier: every rank's tokens are on their way before anybody looks
+  for (int k = 0; k < g->world; k++) good = good && every[k] == 1;
+  int32_t ok = 0;
+  if (good) {
+    hipLaunchKernelGGL(k_link_hello_get, dim3(1), dim3(kWave), 0, st, s.link_buf, g->world, link_hello_at(g), s.link_ok);
+    LP_TRY(check_launch("k_link_hello_get"));
+    HIP_TRY(hipMemcpyAsync(&ok, s.link_ok, sizeof(ok), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  mine[0] = ok == 1 ? 1 : 0;
+  LP_TRY(gather(1));
+  for (int k = 0; k < g->world; k++) good = good && every[k] == 1;
+  g->link = good;
   return LPAMD_OK;
 }
 
@@ -744,6 +964,11 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   if (const char* env = getenv("LPAMD_SHARD_POLL")) g->poll_every = std::max(1, atoi(env));
   g->poll_every = std::min(g->poll_every, g->local_exchange ? 16 : 64);
   if (const char* env = getenv("LPAMD_SHARD_FUSED")) g->fused_step = atoi(env) != 0;
+  // The exchange inside the step's launch: wherever the one-launch step runs (the connect functions look at the engines).
+  // Shards that share a GPU (in-process exchange) order their launches with events on top, see link_fence_local.
+  g->ll_words = 2 * g->slot_words;
+  g->link = g->fused_step && world <= kWave;
+  if (const char* env = getenv("LPAMD_SHARD_LINK")) g->link = g->link && atoi(env) != 0;
   return g;
 }
 
@@ -815,6 +1040,8 @@ int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards
     }
   }
   if (rc == LPAMD_OK) rc = finish_group(g);
+  // (a rehearsal over RCCL takes the road of one process per GPU: handles through the communicator, the three all-gathers)
+  if (rc == LPAMD_OK) rc = (rehearse && !local) ? link_connect_ranks(g, g->shards[0]) : link_connect_local(g);
   (void)hipSetDevice(prev);
   if (rc != LPAMD_OK) {
     char keep[sizeof(g_err)];
@@ -852,6 +1079,7 @@ int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t ran
     }
   }
   if (rc == LPAMD_OK) rc = finish_group(g);
+  if (rc == LPAMD_OK) rc = link_connect_ranks(g, g->shards[0]);
   if (rc != LPAMD_OK) {
     char keep[sizeof(g_err)];
     std::memcpy(keep, g_err, sizeof(keep));
@@ -890,6 +1118,13 @@ int lpamd_group_comm_ranks(lpamd_group* g, int32_t* ranks) {
   int count = 0;
   RCCL_TRY(api, api->CommCount(g->shards[0].comm, &count));
   *ranks = count;
+  return LPAMD_OK;
+}
+
+int lpamd_group_link_active(lpamd_group* g, int32_t* active) {
+  CHECK_GROUP(g);
+  if (!active) return set_err(LPAMD_E_ARG, "group_link_active: null");
+  *active = g->link ? 1 : 0;
   return LPAMD_OK;
 }
 

@@ -14,6 +14,16 @@
 // its workgroups start; a poll that does not complete within kFusedSpinLimit rounds marks the state ST_ERROR.  The
 // state that decides whether the step exists is not written by this launch except by its last writer's own fields (the
 // pivot count travels to the row workgroups inside the first column workgroup's record).
+//
+// The exchange itself can move into the launch as well (kIn / kOut, ShardLink): the row workgroups store the slot straight
+// into every rank's receive buffer over xGMI (peer-mapped device memory) instead of into a send buffer that a collective
+// then carries, and the next step's launch reads what it needs of the ranks' slots from its own buffer.  No flag, counter or
+// fence says "the slot has arrived": every 64-bit payload word travels as TWO tagged words (32 bits of data, 32-bit tag = the
+// number of the exporting launch; each an aligned 8-byte store, which memory keeps whole), and a reader polls exactly the
+// words it consumes until both carry the tag it expects, so arrival and content are one access whatever order the stores land
+// in.  Three receive buffers take turns (tag mod 3): a rank can export tag t+3 only after it has consumed every rank's
+// record of tag t+2, which each rank wrote from a launch that its stream ran after the launch that consumed tag t.  A poll
+// gives up after kLinkTimeoutTicks of the constant 100 MHz clock, marks the state ST_ERROR and leaves: the grid always drains.
 #pragma once
 #include "lpamd_fused_kernels.hip.h"
 
@@ -21,15 +31,80 @@ namespace lpamd {
 
 constexpr int kShardRecWords = 5;        // reduced cost (2), local column (1), pivot count after the step (2; first column workgroup)
 constexpr int kShardMaxColGroups = 384;  // their records are polled by 256 threads, 8 words each at most
+constexpr int kLinkBuffers = 3;
+constexpr long long kLinkTimeoutTicks = 10LL * 100000000LL;   // ten seconds of the 100 MHz clock: a peer may be late by a pass, not by this
+constexpr uint32_t kLinkMaxRounds = 1u << 27;                  // ... and a bound that does not depend on the clock
 
+struct ShardLink {
+  uint64_t* const* peers;   // device array [ranks of the exchange]: every rank's receive buffers as this process maps them
+  const uint64_t* in;       // this rank's own receive buffers
+  int64_t ll_words;         // tagged words per slot (twice the payload words)
+  int32_t my_rank;          // where this rank's slot lives among the slots of a buffer
+  uint32_t tag_in;          // tag of the slots this launch reads (kIn) ...
+  uint32_t tag_out;         // ... and of the slot it writes (kOut)
+};
+
+// payload word -> its pair of tagged words at p[0], p[1] (low half, high half)
+__device__ __forceinline__ void ll_put(uint64_t* p, uint64_t v, uint32_t tag) {
+  __hip_atomic_store(p, (v << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(p + 1, (v & 0xFFFFFFFF00000000ull) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// false: the pair did not carry `tag` in time
+__device__ __forceinline__ bool ll_get(const uint64_t* p, uint32_t tag, uint64_t& v, long long timeout = kLinkTimeoutTicks) {
+  long long t0 = 0;
+  for (uint32_t round = 0; round < kLinkMaxRounds; round++) {
+    const uint64_t a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t b = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if ((uint32_t)a == tag && (uint32_t)b == tag) { v = (a >> 32) | (b & 0xFFFFFFFF00000000ull); return true; }
+    if (round == 64) t0 = wall_clock64();
+    else if (round > 64 && (round & 63) == 0 && wall_clock64() - t0 > timeout) return false;
+    if (round < 16) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
+  }
+  return false;
+}
+// The same for up to kN payload words at once (those whose bit is set in `want`): all their loads are out before the first
+// tag is looked at, so a thread that needs several words pays one round trip to memory, not one per word.
+template <int kN>
+__device__ __forceinline__ bool ll_get_many(const uint64_t* const (&p)[kN], uint32_t tag, uint64_t (&v)[kN], uint32_t want, long long timeout = kLinkTimeoutTicks) {
+  uint32_t pending = want;
+  long long t0 = 0;
+  for (uint32_t round = 0; round < kLinkMaxRounds && pending; round++) {
+    uint64_t a[kN], b[kN];
+#pragma unroll
+    for (int q = 0; q < kN; q++)
+      if ((pending >> q) & 1u) {
+        a[q] = __hip_atomic_load(p[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        b[q] = __hip_atomic_load(p[q] + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+#pragma unroll
+    for (int q = 0; q < kN; q++)
+      if (((pending >> q) & 1u) && (uint32_t)a[q] == tag && (uint32_t)b[q] == tag) {
+        v[q] = (a[q] >> 32) | (b[q] & 0xFFFFFFFF00000000ull);
+        pending &= ~(1u << q);
+      }
+    if (!pending) break;
+    if (round == 64) t0 = wall_clock64();
+    else if (round > 64 && (round & 63) == 0 && wall_clock64() - t0 > timeout) return false;
+    if (round < 16) __builtin_amdgcn_s_sleep(1); else __builtin_amdgcn_s_sleep(8);
+  }
+  return pending == 0;
+}
+__device__ __forceinline__ bool ll_get_f64(const uint64_t* p, uint32_t tag, double& v) {
+  uint64_t b = 0;
+  const bool ok = ll_get(p, tag, b);
+  v = __longlong_as_double((long long)b);
+  return ok;
+}
+
+template <bool kIn, bool kOut>
 __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int n_ratio_part, int n_row_blocks,
     double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, double* __restrict__ rhsv,
     double* __restrict__ obj, const uint8_t* __restrict__ is_basic, const int64_t* __restrict__ basis,
     int64_t* __restrict__ trace, int64_t trace_cap, double* __restrict__ next_pv, int64_t* __restrict__ next_pi,
     const uint64_t* __restrict__ slots, int slot_world, int64_t slot_words, int slot_header, int depth,
-    uint64_t* __restrict__ my_slot,      // nullptr: no slot for a next step (last step of the pass)
-    uint64_t* __restrict__ rec, uint32_t epoch) {
+    uint64_t* __restrict__ my_slot,      // nullptr: no slot for a next step (last step of the pass); kOut: any other value
+    uint64_t* __restrict__ rec, uint32_t epoch, ShardLink link) {
   constexpr int kThreads = kPartialThreads;
   __shared__ double s_v[kThreads / kWave];
   __shared__ int64_t s_i[kThreads / kWave];
@@ -53,7 +128,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   const int64_t max_iter = st->max_iter;
   Candidate c_rec;
   c_rec.key = -DBL_MAX; c_rec.gcol = -1; c_rec.row = -1; c_rec.ce = 0.0;
-  if (slot_world <= kWave && tid < slot_world) c_rec = *reinterpret_cast<const Candidate*>(slots + (size_t)tid * slot_words);
+  if (!kIn && slot_world <= kWave && tid < slot_world) c_rec = *reinterpret_cast<const Candidate*>(slots + (size_t)tid * slot_words);
   int32_t q_in = -1, q_out = -1;
   int64_t q_e = -1, q_r = -1;
   if (lane == 0) { q_in = st->l_e; q_out = st->l_d; q_e = st->e; q_r = st->r; }
@@ -66,6 +141,16 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   if (j == 1 && keeper) for (int s = 1; s < depth; s++) { steps[s].done = 0; steps[s].e = -1; }
   if (!prev_done) return;
   if (dirty_step != 0 && dirty_step - 1 < j) return;
+  bool late = false;                      // kIn: a word this thread needs did not arrive
+  if (kIn && tid < slot_world) {          // (the host admits at most kWave ranks)
+    uint64_t w4[4] = {0, ~0ull, ~0ull, 0};
+    const uint64_t* at = link.in + ((int64_t)(link.tag_in % kLinkBuffers) * slot_world + tid) * link.ll_words;
+    const uint64_t* const p4[4] = {at, at + 2, at + 4, at + 6};
+    late = !ll_get_many<4>(p4, link.tag_in, w4, 0xFu);
+    c_rec.key = __longlong_as_double((long long)w4[0]); c_rec.gcol = (int64_t)w4[1]; c_rec.row = (int64_t)w4[2];
+    c_rec.ce = __longlong_as_double((long long)w4[3]);
+    if (late) c_rec.gcol = -1;
+  }
   // ---- the winner among the ranks' records (larger key, lower global column; reference lp_simplex_tableau.cc:188-198)
   if (slot_world <= kWave) {
     if (tid < kWave) {
@@ -89,21 +174,48 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     }
     s_w = w; s_e2 = best.gcol; s_ce2 = best.ce;
   }
-  __syncthreads();
+  if (kIn) {
+    if (__syncthreads_or(late)) { if (tid == 0) st->status = ST_ERROR; return; }
+  } else {
+    __syncthreads();
+  }
   const int w = s_w;
   if (w < 0) return;                      // optimal after step j-1, or the budget ends with it
-  const uint64_t* __restrict__ mine = slots + (size_t)w * slot_words;
+  const uint64_t* __restrict__ mine = slots + (size_t)(kIn ? 0 : w) * slot_words;
   const int64_t e2 = s_e2;
   const double ce2 = s_ce2;
   const double* __restrict__ colv = reinterpret_cast<const double*>(mine + slot_header);
   const double* __restrict__ rv = colv + sh.lda;      // the owner's ratio-test partials: values, then rows
   const int64_t* __restrict__ ri = reinterpret_cast<const int64_t*>(rv + n_ratio_part);
-  const double colv0 = have_row ? colv[i0] : 0.0;
+  // kIn: the winner's slot in this rank's receive buffer, payload word x at ll_mine[2 * x]
+  const uint64_t* __restrict__ ll_mine = kIn ? link.in + ((int64_t)(link.tag_in % kLinkBuffers) * slot_world + w) * link.ll_words : nullptr;
+  double colv0 = 0.0;
   double best = DBL_MAX;
   int64_t r2 = -1;
-  fold_share<false, kThreads>(rv, ri, n_ratio_part, best, r2);
+  if (kIn) {
+    // this thread's row of the column and its first pair of ratio-test partials in one round trip
+    const uint64_t* part = ll_mine + 2 * ((int64_t)slot_header + sh.lda);
+    {
+      uint64_t w3[3] = {0, 0, ~0ull};
+      const uint64_t* const p3[3] = {ll_mine + 2 * ((int64_t)slot_header + (have_row ? i0 : 0)), part + 2 * (int64_t)tid, part + 2 * ((int64_t)n_ratio_part + tid)};
+      const uint32_t want = (have_row ? 1u : 0u) | (tid < n_ratio_part ? 6u : 0u);
+      late |= !ll_get_many<3>(p3, link.tag_in, w3, want);
+      colv0 = __longlong_as_double((long long)w3[0]);
+      if (!late && tid < n_ratio_part) take_min(best, r2, __longlong_as_double((long long)w3[1]), (int64_t)w3[2]);
+    }
+    for (int k = tid + kThreads; k < n_ratio_part; k += kThreads) {
+      uint64_t w2[2] = {0, ~0ull};
+      const uint64_t* const p2[2] = {part + 2 * (int64_t)k, part + 2 * ((int64_t)n_ratio_part + k)};
+      late |= !ll_get_many<2>(p2, link.tag_in, w2, 3u);
+      if (!late) take_min(best, r2, __longlong_as_double((long long)w2[0]), (int64_t)w2[1]);
+    }
+  } else {
+    colv0 = have_row ? colv[i0] : 0.0;
+    fold_share<false, kThreads>(rv, ri, n_ratio_part, best, r2);
+  }
   block_arg<false, kThreads>(best, r2, s_v, s_i);
-  if (r2 < 0) return;                     // unbounded after step j-1: found again, and reported, by the next iteration
+  if (kIn && __syncthreads_or(late)) { if (tid == 0) st->status = ST_ERROR; return; }
+  if (r2 < 0 || r2 >= sh.m) return;       // unbounded after step j-1: found again, and reported, by the next iteration
   r2 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(r2 >> 32)) << 32) |
                  (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)r2));
   auto local_id = [&](int64_t g) -> int {
@@ -112,7 +224,13 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     return (ord_rank(o, sh.world) == sh.rank) ? ord_local(o, sh.world) : -1;
   };
   const int l_e2 = local_id(e2);
-  const double a2 = colv[r2];
+  double a2 = 0.0;
+  if (kIn) {
+    late = !ll_get_f64(ll_mine + 2 * ((int64_t)slot_header + r2), link.tag_in, a2);
+    if (__syncthreads_or(late)) { if (tid == 0) st->status = ST_ERROR; return; }
+  } else {
+    a2 = colv[r2];
+  }
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
 
@@ -155,11 +273,23 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     const int64_t iter_after = (int64_t)(((uint64_t)s_words[4] << 32) | s_words[3]);
     block_arg<true, kThreads>(ce, lw, s_v, s_i);
     if (iter_after >= max_iter) lw = -1;           // a used-up budget travels as "no candidate"
+    // kOut: where this rank's slot starts in a receive buffer
+    const int64_t out_at = ((int64_t)(link.tag_out % kLinkBuffers) * slot_world + link.my_rank) * link.ll_words;
     if (blockIdx.x == 0 && tid == 0) {
       Candidate c;
       c.key = ce; c.ce = ce; c.row = -1;
       c.gcol = lw < 0 ? -1 : gcol_of(lw * sh.world + sh.rank, sh.N);
-      *reinterpret_cast<Candidate*>(my_slot) = c;
+      if (kOut) {
+        for (int p = 0; p < slot_world; p++) {
+          uint64_t* dst = link.peers[p] + out_at;
+          ll_put(dst, (uint64_t)__double_as_longlong(c.key), link.tag_out);
+          ll_put(dst + 2, (uint64_t)c.gcol, link.tag_out);
+          ll_put(dst + 4, (uint64_t)c.row, link.tag_out);
+          ll_put(dst + 6, (uint64_t)__double_as_longlong(c.ce), link.tag_out);
+        }
+      } else {
+        *reinterpret_cast<Candidate*>(my_slot) = c;
+      }
     }
     double* __restrict__ xlocal = reinterpret_cast<double*>(my_slot + slot_header);
     double* __restrict__ rpart_v = xlocal + sh.lda;
@@ -172,12 +302,32 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     if (lw >= 0 && tid <= j) s_u[tid] = ld_shared_f64(rowp + (int64_t)tid * rstride + l);   // row'_s of the candidate, one round trip
     __syncthreads();
     if (lw >= 0 && have_row) v = fused_chain_reg<true, kMaxChain>(t0, j + 1, s_u, h);
-    if (i0 < sh.lda) xlocal[i0] = v;
+    if (kOut) {
+      if (i0 < sh.lda)
+        for (int p = 0; p < slot_world; p++) ll_put(link.peers[p] + out_at + 2 * ((int64_t)slot_header + i0), (uint64_t)__double_as_longlong(v), link.tag_out);
+    } else if (i0 < sh.lda) {
+      xlocal[i0] = v;
+    }
     double bv = DBL_MAX;
     int64_t bi = -1;
     if (lw >= 0 && have_row && (float)v <= -1e-6f) { bv = rhs_i / (-v); bi = i0; }   // reference lp_simplex_tableau.cc:207-227
     block_arg<false, kThreads>(bv, bi, s_v, s_i);
-    if (tid == 0) { rpart_v[blockIdx.x] = bv; rpart_i[blockIdx.x] = bi; }
+    if (kOut) {
+      // one pair of partials per row workgroup; the first one also fills the pairs no workgroup stands for (every word a
+      // reader may poll must be written)
+      auto put_pair = [&](int k, double pv, int64_t pr) {
+        for (int p = 0; p < slot_world; p++) {
+          uint64_t* dst = link.peers[p] + out_at + 2 * ((int64_t)slot_header + sh.lda);
+          ll_put(dst + 2 * (int64_t)k, (uint64_t)__double_as_longlong(pv), link.tag_out);
+          ll_put(dst + 2 * ((int64_t)n_ratio_part + k), (uint64_t)pr, link.tag_out);
+        }
+      };
+      if (tid == 0) put_pair((int)blockIdx.x, bv, bi);
+      if (blockIdx.x == 0)
+        for (int k = n_row_blocks + tid; k < n_ratio_part; k += kThreads) put_pair(k, DBL_MAX, -1);
+    } else if (tid == 0) {
+      rpart_v[blockIdx.x] = bv; rpart_i[blockIdx.x] = bi;
+    }
     return;
   }
 

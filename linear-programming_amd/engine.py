@@ -97,6 +97,7 @@ def library():
         "lpamd_group_destroy": (ctypes.c_int, [vp]),
         "lpamd_group_shards": (ctypes.c_int, [vp, P(i32), P(i32)]),
         "lpamd_group_comm_ranks": (ctypes.c_int, [vp, P(i32)]),
+        "lpamd_group_link_active": (ctypes.c_int, [vp, P(i32)]),
         "lpamd_group_engine": (ctypes.c_int, [vp, i32, P(vp)]),
         "lpamd_group_chain": (ctypes.c_int, [vp, P(i32)]),
         "lpamd_group_upload": (ctypes.c_int, [vp, vp, i64, vp, vp]),
@@ -464,6 +465,12 @@ class ShardGroup:
         n = ctypes.c_int32()
         _ck(self.L.lpamd_group_comm_ranks(self.h, ctypes.byref(n)))
         return n.value
+
+    def link_active(self):
+        """True when chained MAX_COST steps trade their slots inside the step's launch instead of by a collective."""
+        n = ctypes.c_int32()
+        _ck(self.L.lpamd_group_link_active(self.h, ctypes.byref(n)))
+        return n.value != 0
 
     def chain(self):
         d = ctypes.c_int32()
