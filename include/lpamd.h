@@ -271,6 +271,15 @@ enum {
 int lpamd_comm_unique_id(void* id_out);
 int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards, const int32_t* devices, int32_t flags);
 int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id);
+/* The same with the collective supplied by the CALLER instead of RCCL: a host function that hands every rank the
+ * `bytes` bytes of every rank, in rank order (MPI_Allgather, a gloo all_gather, ...; returns 0 on success).  The library
+ * stages through host memory around it, so this form is for machines or set-ups RCCL does not serve (two ranks on one
+ * GPU, which RCCL refuses: that is how the exchange inside the launches is tested between two processes on a one-GPU
+ * machine), not for speed; steps 2.. of a MAX_COST pass still trade inside their launches where the ranks can map each
+ * other's memory.  No counterpart in the reference. */
+typedef int (*lpamd_host_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes);
+int lpamd_group_create_rank_hosted(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world,
+                                   lpamd_host_allgather_fn gather, void* ctx);
 int lpamd_group_destroy(lpamd_group* g);
 /* shards held by this process / shards of the LP; the engine of a local shard (owned by the group:
  * for traces, statistics and read-back through the lpamd_* calls, not for pivoting) */

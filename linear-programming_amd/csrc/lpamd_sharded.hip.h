@@ -245,6 +245,8 @@ struct lpamd_group {
   bool local_exchange = false;
   bool inline_exchange = true;    // collectives inside a chain run on the engine's stream (nothing to overlap them with)
   bool fused_step = true;         // MAX_COST steps inside a chain: ratio-test partials travel with the slot, two launches per step
+  lpamd_host_allgather_fn host_gather = nullptr;   // the collective, when the caller supplies it (lpamd_group_create_rank_hosted)
+  void* host_ctx = nullptr;
   bool link = false;              // MAX_COST steps 2.. of a chain: the slots travel inside the step's launch, no collective
   int64_t ll_words = 0;           // tagged words per slot
   int chain = 1;                  // pivots per pass of the look-ahead loop
@@ -318,6 +320,16 @@ void abort_comms(Group* g) {
 
 // All-gather of `words` 64-bit words per rank on `stream` (send and recv are device memory).
 int all_gather_words(Group* g, Shard& s, const uint64_t* send, uint64_t* recv, int64_t words, hipStream_t stream) {
+  if (g->host_gather) {   // the caller's collective, staged through host memory; synchronous
+    std::vector<uint64_t> mine((size_t)words), every((size_t)words * g->world);
+    HIP_TRY(hipMemcpyAsync(mine.data(), send, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (g->host_gather(g->host_ctx, mine.data(), every.data(), (int64_t)sizeof(uint64_t) * words) != 0)
+      return set_err(LPAMD_E_STATE, "the caller's all-gather failed");
+    HIP_TRY(hipMemcpyAsync(recv, every.data(), sizeof(uint64_t) * words * g->world, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return LPAMD_OK;
+  }
   if (!g->local_exchange) {
     RcclApi* api = nullptr;
     LP_TRY(rccl_api(&api));
@@ -1054,18 +1066,21 @@ int lpamd_group_create(lpamd_group** out, int64_t m, int64_t N, int32_t n_shards
   return LPAMD_OK;
 }
 
-int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id) {
+static int create_rank_impl(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id,
+                            lpamd_host_allgather_fn gather, void* ctx) {
   if (!out) return set_err(LPAMD_E_ARG, "group_create_rank: out is null");
   *out = nullptr;
   // (world > N + 1 would leave a rank without a column: every rank must see that BEFORE any of them enters ncclCommInitRank)
-  if (m <= 0 || N <= 0 || world <= 0 || world > N + 1 || rank < 0 || rank >= world || !comm_id)
+  if (m <= 0 || N <= 0 || world <= 0 || world > N + 1 || rank < 0 || rank >= world || (!comm_id && !gather))
     return set_err(LPAMD_E_ARG, "group_create_rank: bad arguments m=%lld N=%lld rank=%d world=%d", (long long)m, (long long)N, rank, world);
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return set_err(LPAMD_E_NODEVICE, "no HIP device visible");
   Group* g = new_group(m, N, world, 0);
+  g->host_gather = gather;
+  g->host_ctx = ctx;
   g->shards.resize(1);
   int rc = init_shard(g, g->shards[0], rank, dev);
-  if (rc == LPAMD_OK) {
+  if (rc == LPAMD_OK && !gather) {
     RcclApi* api = nullptr;
     rc = rccl_api(&api);
     if (rc == LPAMD_OK) {
@@ -1089,6 +1104,17 @@ int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t ran
   }
   *out = g;
   return LPAMD_OK;
+}
+
+int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world, const void* comm_id) {
+  if (!comm_id) return set_err(LPAMD_E_ARG, "group_create_rank: no communicator id");
+  return create_rank_impl(out, m, N, rank, world, comm_id, nullptr, nullptr);
+}
+
+int lpamd_group_create_rank_hosted(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world,
+                                   lpamd_host_allgather_fn gather, void* ctx) {
+  if (!gather) return set_err(LPAMD_E_ARG, "group_create_rank_hosted: no all-gather function");
+  return create_rank_impl(out, m, N, rank, world, nullptr, gather, ctx);
 }
 
 int lpamd_group_destroy(lpamd_group* g) {

@@ -94,6 +94,7 @@ def library():
         "lpamd_comm_unique_id": (ctypes.c_int, [vp]),
         "lpamd_group_create": (ctypes.c_int, [P(vp), i64, i64, i32, vp, i32]),
         "lpamd_group_create_rank": (ctypes.c_int, [P(vp), i64, i64, i32, i32, vp]),
+        "lpamd_group_create_rank_hosted": (ctypes.c_int, [P(vp), i64, i64, i32, i32, vp, vp]),
         "lpamd_group_destroy": (ctypes.c_int, [vp]),
         "lpamd_group_shards": (ctypes.c_int, [vp, P(i32), P(i32)]),
         "lpamd_group_comm_ranks": (ctypes.c_int, [vp, P(i32)]),
@@ -407,6 +408,9 @@ class TableauEngine:
         _ck(self.L.lpamd_pivot_shard(self.h, int(d), int(e), int(r), float(ce), ctypes.c_void_p(xbuf_ptr) if xbuf_ptr else None))
 
 
+HOST_ALLGATHER = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64)
+
+
 def comm_unique_id():
     """128-byte RCCL id for ShardGroup.join; made on one rank, delivered to the others by the caller."""
     buf = ctypes.create_string_buffer(128)
@@ -420,11 +424,28 @@ class ShardGroup:
     process (local_exchange=True: device copies instead of RCCL, shards may share a GPU);
     ShardGroup.join(m, N, rank, world, comm_id) is the one-process-per-GPU form."""
 
-    def __init__(self, m, N, n_shards=1, devices=None, local_exchange=False, rehearse_rank0=False, _joined=None):
+    def __init__(self, m, N, n_shards=1, devices=None, local_exchange=False, rehearse_rank0=False, _joined=None, _hosted=None):
         self.L = library()
         self.m, self.N = int(m), int(N)
         self.h = ctypes.c_void_p()
-        if _joined is not None:
+        if _hosted is not None:
+            rank, world, gather = _hosted
+
+            def trampoline(_ctx, send, recv, nbytes):
+                try:
+                    out = gather(ctypes.string_at(send, nbytes))
+                    assert len(out) == nbytes * int(world)
+                    ctypes.memmove(recv, out, len(out))
+                    return 0
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+
+            self._gather_cb = HOST_ALLGATHER(trampoline)   # kept alive as long as the group
+            _ck(self.L.lpamd_group_create_rank_hosted(ctypes.byref(self.h), self.m, self.N, int(rank), int(world),
+                                                      ctypes.cast(self._gather_cb, ctypes.c_void_p), None))
+        elif _joined is not None:
             rank, world, comm_id = _joined
             _ck(self.L.lpamd_group_create_rank(ctypes.byref(self.h), self.m, self.N, int(rank), int(world), comm_id))
         else:
@@ -440,6 +461,12 @@ class ShardGroup:
     @classmethod
     def join(cls, m, N, rank, world, comm_id):
         return cls(m, N, _joined=(rank, world, comm_id))
+
+    @classmethod
+    def join_hosted(cls, m, N, rank, world, gather):
+        """One process per shard with the collective supplied by the caller: gather(bytes) -> the ranks' bytes
+        joined in rank order (lpamd_group_create_rank_hosted)."""
+        return cls(m, N, _hosted=(rank, world, gather))
 
     def close(self):
         if self.h:
