@@ -2152,6 +2152,15 @@ int export_lookahead_ratio(lpamd_engine* e, uint64_t* slot, int header_words) {
   return check_launch("k_export_lookahead");
 }
 
+// export_lookahead_ratio with the slot stored into every rank's receive buffer (link.tag_out) instead of a send buffer.
+int export_lookahead_ratio_link(lpamd_engine* e, int world, int header_words, const ShardLink& link) {
+  if (!link.tag_out || !link.peers || world > kWave) return set_err(LPAMD_E_ARG, "export: bad link");
+  if (!e->price_partials_fresh) LP_TRY(enqueue_price_partial(e));
+  hipLaunchKernelGGL(k_export_lookahead_link, dim3((unsigned)slot_ratio_parts(e)), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->part_v,
+                     e->part_i, e->n_price_part, e->colp, e->rowp, e->rstride, e->steps, e->update_pending ? e->pending_steps : 0, e->rhs_next, world, header_words, link);
+  return check_launch("k_export_lookahead_link");
+}
+
 // The two together: set-up of step `pending_steps` from the gathered slots and, into `next_slot` (nullptr: none), this rank's
 // slot for the step after it (k_shard_step).  link (nullptr: none): the exchange inside the launch; tag_in != 0: the slots
 // are read from this rank's receive buffer, tag_out != 0: the slot goes straight into every rank's receive buffer.

@@ -491,18 +491,25 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
         // one launch and the collective per step: the set-up of step j also leaves this rank's slot for step j+1.
         // With the link, only step 1's slots travel by the collective: from then on the launch stores the slot into every
         // rank's receive buffer and the next launch reads it there (tags: see ShardLink).
-        LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));
+        ShardLink lk{};
+        if (g->link) {
+          lk.peers = s.link_peers;
+          lk.in = s.link_buf;
+          lk.ll_words = g->ll_words;
+          lk.my_rank = s.rank;
+          s.link_tag = s.link_tag + 1 == 0 ? 1 : s.link_tag + 1;
+          lk.tag_out = s.link_tag;
+          LP_TRY(export_lookahead_ratio_link(e, g->world, kSlotHeaderWords, lk));
+        } else {
+          LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));
+        }
         for (int j = 1; j < g->chain; j++) {
           const bool last = j + 1 >= g->chain;
-          if (!g->link || j == 1) LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
+          if (!g->link) LP_TRY(all_gather_words(g, s, s.slot, s.slots, g->slot_words, e->stream));
           else LP_TRY(link_fence_local(g, s, e->stream));
-          ShardLink lk{};
           if (g->link) {
-            lk.peers = s.link_peers;
-            lk.in = s.link_buf;
-            lk.ll_words = g->ll_words;
-            lk.my_rank = s.rank;
-            lk.tag_in = j > 1 ? s.link_tag : 0;
+            lk.tag_in = s.link_tag;
+            lk.tag_out = 0;
             if (!last) { s.link_tag = s.link_tag + 1 == 0 ? 1 : s.link_tag + 1; lk.tag_out = s.link_tag; }
           }
           LP_TRY(chain_step_export_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords, last ? nullptr : s.slot, g->link ? &lk : nullptr));
@@ -857,7 +864,7 @@ int init_shard(Group* g, Shard& s, int rank, int device) {
 int link_connect_local(Group* g) {
   if (!g->link) return LPAMD_OK;
   for (Shard& s : g->shards) g->link = g->link && s.eng->shard_step;
-  if (g->chain < 3) g->link = false;       // nothing to carry: step 1's slots travel by the collective
+  if (g->chain < 2) g->link = false;       // no chained step, nothing to carry
   if (!g->link) return LPAMD_OK;
   std::vector<uint64_t*> peers(g->world, nullptr);
   for (Shard& s : g->shards) peers[s.rank] = s.link_buf;
@@ -906,7 +913,7 @@ int link_connect_ranks(Group* g, Shard& s) {
   hipIpcMemHandle_t h;
   // (g->link is what the environment asked for, the same on every rank; whether THIS rank's engine runs the one-launch
   // step is not, and travels with the handle)
-  if (!s.eng->shard_step || g->chain < 3) mine[0] = 0;
+  if (!s.eng->shard_step || g->chain < 2) mine[0] = 0;
   else if (hipIpcGetMemHandle(&h, s.link_buf) == hipSuccess) { mine[0] = 1; std::memcpy(&mine[1], &h, sizeof(h)); }
   else (void)hipGetLastError();
   auto gather = [&](int words) -> int {

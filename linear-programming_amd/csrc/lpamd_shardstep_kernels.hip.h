@@ -96,6 +96,55 @@ __device__ __forceinline__ bool ll_get_f64(const uint64_t* p, uint32_t tag, doub
   return ok;
 }
 
+// k_export_lookahead<ratio> with the slot stored straight into every rank's receive buffer: this rank's candidate for
+// step 1 of a pass (record, column as the pivots set up so far will leave it, ratio-test partials; one workgroup per 256
+// rows, so every pair of partials has its writer).
+__global__ __launch_bounds__(kPartialThreads) void k_export_lookahead_link(
+    Tab T, Shape sh, const PivotState* __restrict__ st, const double* __restrict__ pv, const int64_t* __restrict__ pi, int n_price_part,
+    const double* __restrict__ colp, const double* __restrict__ rowp, int64_t rstride, const ChainStep* __restrict__ steps, int pending,
+    const double* __restrict__ rhsv, int slot_world, int slot_header, ShardLink link) {
+  __shared__ double s_v[kPartialThreads / kWave];
+  __shared__ int64_t s_i[kPartialThreads / kWave];
+  const int32_t status = st->status;
+  const int64_t iter = st->iter, max_iter = st->max_iter;
+  const int n = pending > 0 ? chain_steps_done(steps, pending) : 0;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const double* __restrict__ rhs = n == 0 ? T.col(sh.nloc) : rhsv + (int64_t)(n - 1) * sh.lda;
+  const double rhs_i = i < sh.m ? rhs[i] : 0.0;
+  double ce = -DBL_MAX;
+  int64_t l = -1;
+  fold_share<true, kPartialThreads>(pv, pi, n_price_part, ce, l);
+  if (status != ST_RUNNING) return;
+  block_arg<true, kPartialThreads>(ce, l, s_v, s_i);
+  if (iter >= max_iter) l = -1;
+  const int64_t out_at = ((int64_t)(link.tag_out % kLinkBuffers) * slot_world + link.my_rank) * link.ll_words;
+  const int n_parts = (int)gridDim.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const int64_t gcol = l < 0 ? -1 : gcol_of(l * sh.world + sh.rank, sh.N);
+    for (int p = 0; p < slot_world; p++) {
+      uint64_t* dst = link.peers[p] + out_at;
+      ll_put(dst, (uint64_t)__double_as_longlong(ce), link.tag_out);
+      ll_put(dst + 2, (uint64_t)gcol, link.tag_out);
+      ll_put(dst + 4, ~0ull, link.tag_out);
+      ll_put(dst + 6, (uint64_t)__double_as_longlong(ce), link.tag_out);
+    }
+  }
+  double v = 0.0;
+  if (l >= 0 && i < sh.m) v = chain_apply(T.col(l)[i], n, colp + i, sh.lda, rowp + l, rstride);
+  if (i < sh.lda)
+    for (int p = 0; p < slot_world; p++) ll_put(link.peers[p] + out_at + 2 * ((int64_t)slot_header + i), (uint64_t)__double_as_longlong(v), link.tag_out);
+  double bv = DBL_MAX;
+  int64_t bi = -1;
+  if (l >= 0 && i < sh.m && (float)v <= -1e-6f) { bv = rhs_i / (-v); bi = i; }   // reference lp_simplex_tableau.cc:207-227
+  block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
+  if (threadIdx.x == 0)
+    for (int p = 0; p < slot_world; p++) {
+      uint64_t* dst = link.peers[p] + out_at + 2 * ((int64_t)slot_header + sh.lda);
+      ll_put(dst + 2 * (int64_t)blockIdx.x, (uint64_t)__double_as_longlong(bv), link.tag_out);
+      ll_put(dst + 2 * ((int64_t)n_parts + blockIdx.x), (uint64_t)bi, link.tag_out);
+    }
+}
+
 template <bool kIn, bool kOut>
 __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int n_ratio_part, int n_row_blocks,

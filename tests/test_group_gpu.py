@@ -59,16 +59,15 @@ def test_group_budgets_end_inside_a_chain(lpamd, monkeypatch, world, chain, fuse
     shards long enough (m > 2048 rows) that the exchange stream really runs beside the pass.
     fused: a chained step is set up straight from the gathered slots (the ratio-test partials travel with
     the column), 2: by the one launch that also writes the rank's slot for the step after it (k_shard_step, several
-    shards only), 3: that launch also stores the slot into every shard's receive buffer, no collective from step 2 on
-    (a chain of three and more); 1: by a set-up launch and an export launch; 0: with the fold kernel and a
+    shards only), 3: the launches also store the slots into every shard's receive buffer, no collective inside a chain; 1: by a set-up launch and an export launch; 0: with the fold kernel and a
     ratio-test launch of its own."""
     m, n, seed, legs = 2560, 3072, 7, (23, 1, 40, 0, 9)
     if chain == 1 and fused != 1:
         pytest.skip("a chain of one has no chained step")
     if world == 1 and fused >= 2:
         pytest.skip("one shard never takes the one-launch step")
-    if fused == 3 and chain < 3:
-        pytest.skip("the slots travel inside the launch only from step 2 on")
+    if fused == 3 and chain < 2:
+        pytest.skip("a chain of one has no chained step")
     monkeypatch.setenv("LPAMD_SHARD_CHAIN", str(chain))
     monkeypatch.setenv("LPAMD_SHARD_FUSED", str(min(fused, 1)))
     monkeypatch.setenv("LPAMD_SHARD_STEP", "1" if fused >= 2 else "0")
