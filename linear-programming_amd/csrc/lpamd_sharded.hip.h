@@ -985,7 +985,7 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   if (const char* env = getenv("LPAMD_SHARD_FUSED")) g->fused_step = atoi(env) != 0;
   // The exchange inside the step's launch: wherever the one-launch step runs (the connect functions look at the engines).
   // Shards that share a GPU (in-process exchange) order their launches with events on top, see link_fence_local.
-  g->ll_words = 2 * g->slot_words;
+  g->ll_words = 2 * (g->slot_words + (g->lda + kPartialThreads - 1) / kPartialThreads);   // + the column's entry at the row of every ratio-test partial
   g->link = g->fused_step && world <= kWave;
   if (const char* env = getenv("LPAMD_SHARD_LINK")) g->link = g->link && atoi(env) != 0;
   return g;

@@ -137,11 +137,12 @@ __global__ __launch_bounds__(kPartialThreads) void k_export_lookahead_link(
   int64_t bi = -1;
   if (l >= 0 && i < sh.m && (float)v <= -1e-6f) { bv = rhs_i / (-v); bi = i; }   // reference lp_simplex_tableau.cc:207-227
   block_arg<false, kPartialThreads>(bv, bi, s_v, s_i);
-  if (threadIdx.x == 0)
+  if (bi >= 0 ? i == bi : threadIdx.x == 0)     // the thread that owns the winning row holds the column's entry there
     for (int p = 0; p < slot_world; p++) {
       uint64_t* dst = link.peers[p] + out_at + 2 * ((int64_t)slot_header + sh.lda);
       ll_put(dst + 2 * (int64_t)blockIdx.x, (uint64_t)__double_as_longlong(bv), link.tag_out);
       ll_put(dst + 2 * ((int64_t)n_parts + blockIdx.x), (uint64_t)bi, link.tag_out);
+      ll_put(dst + 2 * (2 * (int64_t)n_parts + blockIdx.x), (uint64_t)__double_as_longlong(bi >= 0 ? v : 0.0), link.tag_out);
     }
 }
 
@@ -160,12 +161,17 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   __shared__ int s_w;
   __shared__ int64_t s_e2;
   __shared__ double s_ce2;
+  __shared__ double s_a2;
   __shared__ uint32_t s_words[8 * kThreads];
   __shared__ __attribute__((aligned(16))) double s_u[kMaxChain];
   const int tid = threadIdx.x, lane = tid & (kWave - 1);
   const bool row_block = (int)blockIdx.x < n_row_blocks;
   const int cb = (int)blockIdx.x - n_row_blocks, n_cb = (int)gridDim.x - n_row_blocks;
   const int ncl = sh.nloc + 1;
+  LPAMD_CLKR_DECL;
+  const int clk_who = blockIdx.x == 0 ? 0 : cb == 0 ? 2 : cb == n_cb - 1 ? 3 : -1;   // timeline (experiments only): who this workgroup is
+  (void)clk_who;
+  LPAMD_CLKR(0, clk_who >= 0);
   const uint32_t tag = (epoch << 8) | 1u;
   const int64_t region = fused_region_words(n_cb, kShardRecWords);
   const double* __restrict__ rhs_prev = rhsv + (int64_t)(j - 1) * sh.lda;
@@ -178,6 +184,17 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   Candidate c_rec;
   c_rec.key = -DBL_MAX; c_rec.gcol = -1; c_rec.row = -1; c_rec.ce = 0.0;
   if (!kIn && slot_world <= kWave && tid < slot_world) c_rec = *reinterpret_cast<const Candidate*>(slots + (size_t)tid * slot_words);
+  // kIn: a first look at the ranks' records goes out with the loads above (whether the step exists at all is only known
+  // once those are back, and a step that does not exist must not wait for records nobody sends)
+  const uint64_t* rec_at = kIn ? link.in + ((int64_t)(link.tag_in % kLinkBuffers) * slot_world + (tid < slot_world ? tid : 0)) * link.ll_words : nullptr;
+  uint64_t first_a[4] = {0, 0, 0, 0}, first_b[4] = {0, 0, 0, 0};
+  if (kIn && tid < slot_world) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      first_a[q] = __hip_atomic_load(rec_at + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      first_b[q] = __hip_atomic_load(rec_at + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   int32_t q_in = -1, q_out = -1;
   int64_t q_e = -1, q_r = -1;
   if (lane == 0) { q_in = st->l_e; q_out = st->l_d; q_e = st->e; q_r = st->r; }
@@ -193,9 +210,16 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   bool late = false;                      // kIn: a word this thread needs did not arrive
   if (kIn && tid < slot_world) {          // (the host admits at most kWave ranks)
     uint64_t w4[4] = {0, ~0ull, ~0ull, 0};
-    const uint64_t* at = link.in + ((int64_t)(link.tag_in % kLinkBuffers) * slot_world + tid) * link.ll_words;
-    const uint64_t* const p4[4] = {at, at + 2, at + 4, at + 6};
-    late = !ll_get_many<4>(p4, link.tag_in, w4, 0xFu);
+    uint32_t missing = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if ((uint32_t)first_a[q] == link.tag_in && (uint32_t)first_b[q] == link.tag_in) w4[q] = (first_a[q] >> 32) | (first_b[q] & 0xFFFFFFFF00000000ull);
+      else missing |= 1u << q;
+    }
+    if (missing) {
+      const uint64_t* const p4[4] = {rec_at, rec_at + 2, rec_at + 4, rec_at + 6};
+      late = !ll_get_many<4>(p4, link.tag_in, w4, missing);
+    }
     c_rec.key = __longlong_as_double((long long)w4[0]); c_rec.gcol = (int64_t)w4[1]; c_rec.row = (int64_t)w4[2];
     c_rec.ce = __longlong_as_double((long long)w4[3]);
     if (late) c_rec.gcol = -1;
@@ -229,6 +253,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     __syncthreads();
   }
   const int w = s_w;
+  LPAMD_CLKR(1, clk_who >= 0);
   if (w < 0) return;                      // optimal after step j-1, or the budget ends with it
   const uint64_t* __restrict__ mine = slots + (size_t)(kIn ? 0 : w) * slot_words;
   const int64_t e2 = s_e2;
@@ -241,23 +266,37 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   double colv0 = 0.0;
   double best = DBL_MAX;
   int64_t r2 = -1;
+  double my_a = 0.0;      // kIn: the winner's column at the row of this thread's best partial
+  int64_t my_r = -1;
   if (kIn) {
-    // this thread's row of the column and its first pair of ratio-test partials in one round trip
+    // this thread's row of the column and its first triple of ratio-test partials (ratio, row, the column's entry at that
+    // row) in one round trip; the entry travels with the partial so that the pivot element needs no read of its own
     const uint64_t* part = ll_mine + 2 * ((int64_t)slot_header + sh.lda);
     {
-      uint64_t w3[3] = {0, 0, ~0ull};
-      const uint64_t* const p3[3] = {ll_mine + 2 * ((int64_t)slot_header + (have_row ? i0 : 0)), part + 2 * (int64_t)tid, part + 2 * ((int64_t)n_ratio_part + tid)};
-      const uint32_t want = (have_row ? 1u : 0u) | (tid < n_ratio_part ? 6u : 0u);
-      late |= !ll_get_many<3>(p3, link.tag_in, w3, want);
-      colv0 = __longlong_as_double((long long)w3[0]);
-      if (!late && tid < n_ratio_part) take_min(best, r2, __longlong_as_double((long long)w3[1]), (int64_t)w3[2]);
+      uint64_t w4[4] = {0, 0, ~0ull, 0};
+      const uint64_t* const p4[4] = {ll_mine + 2 * ((int64_t)slot_header + (have_row ? i0 : 0)), part + 2 * (int64_t)tid,
+                                     part + 2 * ((int64_t)n_ratio_part + tid), part + 2 * (2 * (int64_t)n_ratio_part + tid)};
+      const uint32_t want = (have_row ? 1u : 0u) | (tid < n_ratio_part ? 14u : 0u);
+      late |= !ll_get_many<4>(p4, link.tag_in, w4, want);
+      colv0 = __longlong_as_double((long long)w4[0]);
+      if (!late && tid < n_ratio_part) {
+        const double pv = __longlong_as_double((long long)w4[1]);
+        const int64_t before = r2;
+        take_min(best, r2, pv, (int64_t)w4[2]);
+        if (r2 != before) my_a = __longlong_as_double((long long)w4[3]);
+      }
     }
     for (int k = tid + kThreads; k < n_ratio_part; k += kThreads) {
-      uint64_t w2[2] = {0, ~0ull};
-      const uint64_t* const p2[2] = {part + 2 * (int64_t)k, part + 2 * ((int64_t)n_ratio_part + k)};
-      late |= !ll_get_many<2>(p2, link.tag_in, w2, 3u);
-      if (!late) take_min(best, r2, __longlong_as_double((long long)w2[0]), (int64_t)w2[1]);
+      uint64_t w3[3] = {0, ~0ull, 0};
+      const uint64_t* const p3[3] = {part + 2 * (int64_t)k, part + 2 * ((int64_t)n_ratio_part + k), part + 2 * (2 * (int64_t)n_ratio_part + k)};
+      late |= !ll_get_many<3>(p3, link.tag_in, w3, 7u);
+      if (!late) {
+        const int64_t before = r2;
+        take_min(best, r2, __longlong_as_double((long long)w3[0]), (int64_t)w3[1]);
+        if (r2 != before) my_a = __longlong_as_double((long long)w3[2]);
+      }
     }
+    my_r = r2;
   } else {
     colv0 = have_row ? colv[i0] : 0.0;
     fold_share<false, kThreads>(rv, ri, n_ratio_part, best, r2);
@@ -275,13 +314,15 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   const int l_e2 = local_id(e2);
   double a2 = 0.0;
   if (kIn) {
-    late = !ll_get_f64(ll_mine + 2 * ((int64_t)slot_header + r2), link.tag_in, a2);
-    if (__syncthreads_or(late)) { if (tid == 0) st->status = ST_ERROR; return; }
+    if (my_r == r2) s_a2 = my_a;           // exactly one partial stands for row r2
+    __syncthreads();
+    a2 = s_a2;
   } else {
     a2 = colv[r2];
   }
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
+  LPAMD_CLKR(2, clk_who >= 0);
 
   if (row_block) {
     // ---- col'_j and the right-hand side after the step for this thread's row
@@ -294,7 +335,8 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
       rhsv[(int64_t)j * sh.lda + i0] = rhs_i;
       if (!(fabs(cpi) < kDirtyBound)) st->dirty_step = j + 1;   // PivotState::dirty
     }
-    if (!my_slot) return;
+    LPAMD_CLKR(3, clk_who >= 0);
+    if (!my_slot) { LPAMD_CLKR_FLUSH(j, clk_who, clk_who >= 0); return; }
     // ---- this rank's slot for step j+1.  While the column workgroups are at work: col'_s of this thread's row for the
     // steps so far, into registers (they do not depend on which column the candidate will be)
     double h[kMaxChain];
@@ -313,6 +355,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     // The pricing after step j: the column workgroups' records
     const bool ok = poll_words<8>(rec + (int64_t)((int)blockIdx.x % kFusedReplicas) * region, n_cb * kShardRecWords, tag, tid, kThreads, s_words);
     if (__syncthreads_or(!ok)) { if (tid == 0) st->status = ST_ERROR; return; }
+    LPAMD_CLKR(4, clk_who >= 0);
     double ce = -DBL_MAX;
     int64_t lw = -1;
     for (int k = tid; k < n_cb; k += kThreads) {
@@ -357,6 +400,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     } else if (i0 < sh.lda) {
       xlocal[i0] = v;
     }
+    LPAMD_CLKR(5, clk_who >= 0);
     double bv = DBL_MAX;
     int64_t bi = -1;
     if (lw >= 0 && have_row && (float)v <= -1e-6f) { bv = rhs_i / (-v); bi = i0; }   // reference lp_simplex_tableau.cc:207-227
@@ -364,19 +408,23 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     if (kOut) {
       // one pair of partials per row workgroup; the first one also fills the pairs no workgroup stands for (every word a
       // reader may poll must be written)
-      auto put_pair = [&](int k, double pv, int64_t pr) {
+      auto put_triple = [&](int k, double pv, int64_t pr, double pa) {
         for (int p = 0; p < slot_world; p++) {
           uint64_t* dst = link.peers[p] + out_at + 2 * ((int64_t)slot_header + sh.lda);
           ll_put(dst + 2 * (int64_t)k, (uint64_t)__double_as_longlong(pv), link.tag_out);
           ll_put(dst + 2 * ((int64_t)n_ratio_part + k), (uint64_t)pr, link.tag_out);
+          ll_put(dst + 2 * (2 * (int64_t)n_ratio_part + k), (uint64_t)__double_as_longlong(pa), link.tag_out);
         }
       };
-      if (tid == 0) put_pair((int)blockIdx.x, bv, bi);
+      if (bi >= 0 && i0 == bi) put_triple((int)blockIdx.x, bv, bi, v);      // the thread that owns the winning row holds the entry
+      if (bi < 0 && tid == 0) put_triple((int)blockIdx.x, DBL_MAX, -1, 0.0);
       if (blockIdx.x == 0)
-        for (int k = n_row_blocks + tid; k < n_ratio_part; k += kThreads) put_pair(k, DBL_MAX, -1);
+        for (int k = n_row_blocks + tid; k < n_ratio_part; k += kThreads) put_triple(k, DBL_MAX, -1, 0.0);
     } else if (tid == 0) {
       rpart_v[blockIdx.x] = bv; rpart_i[blockIdx.x] = bi;
     }
+    LPAMD_CLKR(6, clk_who >= 0);
+    LPAMD_CLKR_FLUSH(j, clk_who, clk_who >= 0);
     return;
   }
 
@@ -408,6 +456,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
       if (!basic && is_pos(o) && o > nbv) { nbv = o; nbi = l; }
     }
   }
+  LPAMD_CLKR(3, clk_who >= 0);
   wait_stores();                          // row'_j is out before this workgroup's record
   block_arg<true, kThreads>(nbv, nbi, s_v, s_i);
   __shared__ int64_t s_iter;
@@ -422,6 +471,8 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
                         : x == 3 ? (uint32_t)(uint64_t)iter_after : (uint32_t)((uint64_t)iter_after >> 32);
     rec_put(rec + (int64_t)(tid / kShardRecWords) * region + (int64_t)cb * kShardRecWords + x, word, tag);
   }
+  LPAMD_CLKR(4, clk_who >= 0);
+  LPAMD_CLKR_FLUSH(j, clk_who, clk_who >= 0);
   if (keeper) {
     ChainStep z;
     z.done = 1; z.slot = 0; z.l_in = l_e2; z.l_out = l_d2;
