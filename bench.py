@@ -232,9 +232,9 @@ def main():
         run = lambda k: group.run_pivots(strat, k)
         depth = min(group.chain(), eng.loop_depth(strat))   # MAX_REDUCTION passes may be shorter than MAX_COST ones
         link = group.link_active()
-        exchange = ("steps 2.. of a pass: every rank stores its slot (record + candidate column + its ratio-test partials, tagged words) into the "
-                    "peers' receive buffers from inside the step's own launch, no collective; step 1 of a pass and the pass boundary: one "
-                    "RCCL all-gather each" if link else
+        exchange = ("inside a pass every rank stores its slot (record + candidate column + its ratio-test partials, tagged words) into the "
+                    "peers' receive buffers from inside the step's own launch, no collective; at the pass boundary one RCCL all-gather "
+                    "beside the pass kernel" if link else
                     "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library")
 
     K, W = args.steps, args.warmup

@@ -275,7 +275,7 @@ int lpamd_group_create_rank(lpamd_group** out, int64_t m, int64_t N, int32_t ran
  * `bytes` bytes of every rank, in rank order (MPI_Allgather, a gloo all_gather, ...; returns 0 on success).  The library
  * stages through host memory around it, so this form is for machines or set-ups RCCL does not serve (two ranks on one
  * GPU, which RCCL refuses: that is how the exchange inside the launches is tested between two processes on a one-GPU
- * machine), not for speed; steps 2.. of a MAX_COST pass still trade inside their launches where the ranks can map each
+ * machine), not for speed; the steps of a MAX_COST pass still trade inside their launches where the ranks can map each
  * other's memory.  No counterpart in the reference. */
 typedef int (*lpamd_host_allgather_fn)(void* ctx, const void* send, void* recv, int64_t bytes);
 int lpamd_group_create_rank_hosted(lpamd_group** out, int64_t m, int64_t N, int32_t rank, int32_t world,
@@ -287,9 +287,9 @@ int lpamd_group_shards(const lpamd_group* g, int32_t* n_local, int32_t* world);
 /* ranks the RCCL communicator of the first local shard really holds (ncclCommCount; 0 with the in-process exchange):
  * what a multi-GPU run reports so that a mis-formed communicator is seen, not inferred */
 int lpamd_group_comm_ranks(lpamd_group* g, int32_t* ranks);
-/* 1 when steps 2.. of a MAX_COST chain trade their slots INSIDE the step's launch (stores into the peers' receive buffers
- * over xGMI, tagged words, no collective; only step 1 of a pass and the pass boundary keep the all-gather), 0 when every
- * step runs the all-gather.  Decided when the group is formed: the ranks map each other's buffers (peer access inside one
+/* 1 when the steps of a MAX_COST chain trade their slots INSIDE the launches (stores into the peers' receive buffers
+ * over xGMI, tagged words, no collective; only the pass boundary keeps the all-gather), 0 when every step runs the
+ * all-gather.  Decided when the group is formed: the ranks map each other's buffers (peer access inside one
  * process, IPC handles traded through the communicator otherwise), run a self-test and agree on the outcome;
  * LPAMD_SHARD_LINK=0 keeps the collective.  No counterpart in the reference (its tableau lives in one address space). */
 int lpamd_group_link_active(lpamd_group* g, int32_t* active);

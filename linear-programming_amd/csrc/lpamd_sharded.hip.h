@@ -247,11 +247,11 @@ struct lpamd_group {
   bool fused_step = true;         // MAX_COST steps inside a chain: ratio-test partials travel with the slot, two launches per step
   lpamd_host_allgather_fn host_gather = nullptr;   // the collective, when the caller supplies it (lpamd_group_create_rank_hosted)
   void* host_ctx = nullptr;
-  bool link = false;              // MAX_COST steps 2.. of a chain: the slots travel inside the step's launch, no collective
+  bool link = false;              // MAX_COST steps of a chain: the slots travel inside the launches, no collective
   int64_t ll_words = 0;           // tagged words per slot
   int chain = 1;                  // pivots per pass of the look-ahead loop
   int chain_mr = 1;               // ... and of the MAX_REDUCTION loop
-  int poll_every = 64;
+  int poll_every = 256;
   std::vector<lpamd_shard> shards;           // the shards this process holds
   std::vector<const void*> pub;              // in-process exchange: what every rank offers
   HostBarrier barrier;
@@ -489,8 +489,8 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
       LP_TRY(lpamd_lookahead_setup(e, s.xbuf));
       if (g->fused_step && e->shard_step && g->chain > 1) {
         // one launch and the collective per step: the set-up of step j also leaves this rank's slot for step j+1.
-        // With the link, only step 1's slots travel by the collective: from then on the launch stores the slot into every
-        // rank's receive buffer and the next launch reads it there (tags: see ShardLink).
+        // With the link there is no collective either: every launch stores its slot into every rank's receive buffer and the
+        // next launch reads it there (tags: see ShardLink); the slot for step 1 comes from k_export_lookahead_link.
         ShardLink lk{};
         if (g->link) {
           lk.peers = s.link_peers;
@@ -976,12 +976,13 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   // The in-process exchange enqueues 2 event records and `world` device copies per shard and pivot.  With 8 shards on
   // one GPU and 64 pivots between two reads of the pivot state, that backlog was seen to exhaust something in the
   // driver that every process on the machine needs (other processes' HSA start-up crashed until the backlog had
-  // drained); 16 pivots between reads keep it short.  RCCL exchanges enqueue one collective per pivot and keep 64.
+  // drained); 16 pivots between reads keep it short.  RCCL exchanges enqueue one collective per pivot at most and read the
+  // state every 256 pivots (a read drains the stream: rank 0 of 8 of m=32768 n=65536 walks 20.8 k pivots/s at 64, 21.0 k at 256).
   // Every cross-stream event wait is a barrier packet with a completion signal of its own in the queue, so the likely
   // resource is the runtime's pool of signals / the queue's packet ring.  The bound holds whatever the environment asks for.
   if (g->local_exchange) g->poll_every = 16;
   if (const char* env = getenv("LPAMD_SHARD_POLL")) g->poll_every = std::max(1, atoi(env));
-  g->poll_every = std::min(g->poll_every, g->local_exchange ? 16 : 64);
+  g->poll_every = std::min(g->poll_every, g->local_exchange ? 16 : 256);
   if (const char* env = getenv("LPAMD_SHARD_FUSED")) g->fused_step = atoi(env) != 0;
   // The exchange inside the step's launch: wherever the one-launch step runs (the connect functions look at the engines).
   // Shards that share a GPU (in-process exchange) order their launches with events on top, see link_fence_local.

@@ -56,6 +56,11 @@ done
 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --strategy max_reduction --steps 256 --warmup 64 --no-cpu-baseline > $o/shard_of_8_max_reduction.json 2>> $o/err.log
 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --config synthetic_m65536_n262144 --strategy max_reduction --steps 64 --warmup 32 --no-cpu-baseline > $o/shard_of_8_m65536_n262144_max_reduction.json 2>> $o/err.log
 LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_cost --steps 512 --warmup 64
+# the same with the RCCL all-gather in front of every chained step instead of the exchange inside the launches
+LPAMD_SHARD_LINK=0 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --steps 512 --warmup 64 --no-cpu-baseline > $o/shard_of_8_max_cost_collective.json 2>> $o/err.log
+LPAMD_SHARD_LINK=0 LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_cost_collective --steps 512 --warmup 64
+# two processes on this GPU trading tagged words through IPC-mapped uncached memory while both kernels run
+[ -x bin_scratch/link_pingpong ] && { timeout -k 10 60 ./bin_scratch/link_pingpong 2000 4096; timeout -k 10 60 ./bin_scratch/link_pingpong 2000 64; } > $o/link_pingpong_two_processes.txt 2>> $o/err.log
 # depth of the chain against the pass kernel (k_update_deep from 17 steps on; 16 and below: k_update_slab)
 for d in 12 16 18 20 22 23 24 26 28 32; do
   LPAMD_CHAIN=$d timeout -k 10 200 python3 -u bench.py --steps $((d*6)) --warmup $d --no-cpu-baseline 2>> $o/err.log | python3 -c "
@@ -79,6 +84,9 @@ if [ -f bin_scratch/liblpamd_dbgclock.so ]; then
   for cfg in synthetic_m32768_n65536 synthetic_m4096_n8192; do
     LPAMD_LIBRARY=bin_scratch/liblpamd_dbgclock.so timeout -k 10 200 python3 scripts/fused_timeline.py $cfg > $o/fused_setup_timeline_${cfg#synthetic_}.txt 2>> $o/err.log
     LPAMD_LIBRARY=bin_scratch/liblpamd_dbgclock.so timeout -k 10 200 python3 scripts/prb_timeline.py $cfg > $o/max_reduction_setup_timeline_${cfg#synthetic_}.txt 2>> $o/err.log
+  done
+  for l in 1 0; do
+    LPAMD_SHARD_LINK=$l LPAMD_LIBRARY=bin_scratch/liblpamd_dbgclock.so timeout -k 10 200 python3 scripts/shard_timeline.py 8 2>> $o/err.log | grep -v "^RCCL\|^HIP\|^ROCm\|^Hostname\|^Librccl" > $o/shard_step_timeline_rank0_of_8_link$l.txt
   done
 fi
 python3 - <<'PY'
