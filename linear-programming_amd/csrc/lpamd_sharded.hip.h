@@ -234,6 +234,7 @@ struct lpamd_shard {   // one column shard of a group and its exchange state
   int32_t* link_ok = nullptr;                // result of the self-test
   std::vector<void*> link_mapped;            // peers' buffers opened through IPC handles
   uint32_t link_tag = 0;                     // tag of the last slot exported that way
+  int64_t link_exports = 0;                  // slots exported that way so far
   int rc = LPAMD_OK;
   std::string err;
 };
@@ -249,6 +250,8 @@ struct lpamd_group {
   void* host_ctx = nullptr;
   bool link = false;              // MAX_COST steps of a chain: the slots travel inside the launches, no collective
   int64_t ll_words = 0;           // tagged words per slot
+  long long link_timeout = 0;     // ticks a reader waits for a word (0: the kernels' default of ten seconds; LPAMD_LINK_TIMEOUT_MS)
+  int64_t link_fault_at = 0;      // experiments only (LPAMD_LINK_FAULT=n): rank 0 mis-tags its n-th slot, which the other ranks then never see
   int chain = 1;                  // pivots per pass of the look-ahead loop
   int chain_mr = 1;               // ... and of the MAX_REDUCTION loop
   int poll_every = 256;
@@ -448,6 +451,13 @@ int export_lookahead(Shard& s) {
   return lpamd_lookahead_export(s.eng, s.slot, s.slot + kSlotHeaderWords);
 }
 
+// The tag the next exported slot carries (s.link_tag, which every rank expects), or a wrong one when a fault was asked for.
+uint32_t link_tag_out(Group* g, Shard& s) {
+  s.link_exports++;
+  if (g->link_fault_at > 0 && s.rank == 0 && s.link_exports == g->link_fault_at) return s.link_tag ^ 0x40000000u;
+  return s.link_tag;
+}
+
 // With the exchange inside the launches a rank can end up in ST_ERROR alone (a slot that did not arrive in time), and the
 // ranks would then leave the loop at different reads of the state, one of them with collectives enqueued that the other
 // never joins.  So the ranks of a communicator trade what they have read and all stop as soon as one has stopped.
@@ -497,8 +507,9 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
           lk.in = s.link_buf;
           lk.ll_words = g->ll_words;
           lk.my_rank = s.rank;
+          lk.timeout = g->link_timeout;
           s.link_tag = s.link_tag + 1 == 0 ? 1 : s.link_tag + 1;
-          lk.tag_out = s.link_tag;
+          lk.tag_out = link_tag_out(g, s);
           LP_TRY(export_lookahead_ratio_link(e, g->world, kSlotHeaderWords, lk));
         } else {
           LP_TRY(export_lookahead_ratio(e, s.slot, kSlotHeaderWords));
@@ -510,7 +521,7 @@ int run_lookahead(Group* g, Shard& s, int64_t k, int32_t* result, int64_t* done)
           if (g->link) {
             lk.tag_in = s.link_tag;
             lk.tag_out = 0;
-            if (!last) { s.link_tag = s.link_tag + 1 == 0 ? 1 : s.link_tag + 1; lk.tag_out = s.link_tag; }
+            if (!last) { s.link_tag = s.link_tag + 1 == 0 ? 1 : s.link_tag + 1; lk.tag_out = link_tag_out(g, s); }
           }
           LP_TRY(chain_step_export_from_slots(e, s.slots, g->world, g->slot_words, kSlotHeaderWords, last ? nullptr : s.slot, g->link ? &lk : nullptr));
         }
@@ -989,6 +1000,8 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   g->ll_words = 2 * (g->slot_words + (g->lda + kPartialThreads - 1) / kPartialThreads);   // + the column's entry at the row of every ratio-test partial
   g->link = g->fused_step && world <= kWave;
   if (const char* env = getenv("LPAMD_SHARD_LINK")) g->link = g->link && atoi(env) != 0;
+  if (const char* env = getenv("LPAMD_LINK_TIMEOUT_MS")) g->link_timeout = std::max(1, atoi(env)) * 100000LL;
+  if (const char* env = getenv("LPAMD_LINK_FAULT")) g->link_fault_at = atoll(env);
   return g;
 }
 

@@ -42,6 +42,7 @@ struct ShardLink {
   int32_t my_rank;          // where this rank's slot lives among the slots of a buffer
   uint32_t tag_in;          // tag of the slots this launch reads (kIn) ...
   uint32_t tag_out;         // ... and of the slot it writes (kOut)
+  long long timeout;        // ticks of the 100 MHz clock a reader waits for a word (0: kLinkTimeoutTicks)
 };
 
 // payload word -> its pair of tagged words at p[0], p[1] (low half, high half)
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     }
     if (missing) {
       const uint64_t* const p4[4] = {rec_at, rec_at + 2, rec_at + 4, rec_at + 6};
-      late = !ll_get_many<4>(p4, link.tag_in, w4, missing);
+      late = !ll_get_many<4>(p4, link.tag_in, w4, missing, link.timeout ? link.timeout : kLinkTimeoutTicks);
     }
     c_rec.key = __longlong_as_double((long long)w4[0]); c_rec.gcol = (int64_t)w4[1]; c_rec.row = (int64_t)w4[2];
     c_rec.ce = __longlong_as_double((long long)w4[3]);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
       const uint64_t* const p4[4] = {ll_mine + 2 * ((int64_t)slot_header + (have_row ? i0 : 0)), part + 2 * (int64_t)tid,
                                      part + 2 * ((int64_t)n_ratio_part + tid), part + 2 * (2 * (int64_t)n_ratio_part + tid)};
       const uint32_t want = (have_row ? 1u : 0u) | (tid < n_ratio_part ? 14u : 0u);
-      late |= !ll_get_many<4>(p4, link.tag_in, w4, want);
+      late |= !ll_get_many<4>(p4, link.tag_in, w4, want, link.timeout ? link.timeout : kLinkTimeoutTicks);
       colv0 = __longlong_as_double((long long)w4[0]);
       if (!late && tid < n_ratio_part) {
         const double pv = __longlong_as_double((long long)w4[1]);
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
     for (int k = tid + kThreads; k < n_ratio_part; k += kThreads) {
       uint64_t w3[3] = {0, ~0ull, 0};
       const uint64_t* const p3[3] = {part + 2 * (int64_t)k, part + 2 * ((int64_t)n_ratio_part + k), part + 2 * (2 * (int64_t)n_ratio_part + k)};
-      late |= !ll_get_many<3>(p3, link.tag_in, w3, 7u);
+      late |= !ll_get_many<3>(p3, link.tag_in, w3, 7u, link.timeout ? link.timeout : kLinkTimeoutTicks);
       if (!late) {
         const int64_t before = r2;
         take_min(best, r2, __longlong_as_double((long long)w3[0]), (int64_t)w3[1]);

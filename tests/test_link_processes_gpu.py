@@ -87,3 +87,35 @@ def test_full_size_ranks_in_processes_of_their_own(lpamd, tmp_path):
     for s in seen:
         assert s["trace"] == want, "rank %d walked other pivots" % s["rank"]
         assert s["rhs"] == rhs, "rank %d: right-hand side differs from the single engine's" % s["rank"]
+
+
+def test_a_slot_that_never_arrives_ends_the_run_on_every_rank(lpamd, tmp_path):
+    """Rank 0 mis-tags its fifth slot (LPAMD_LINK_FAULT): the other rank's launch gives up after the time limit, both ranks
+    learn of it at the next read of the state and stop with LPAMD_ERROR, nobody is left waiting; new groups that keep the
+    collective then walk the oracle's pivots (the fallback of bench.py)."""
+    m, n, seed, legs, world, chain = 2560, 3072, 7, (23, 40), 2, 8
+    env = dict(os.environ, LPAMD_SHARD_CHAIN=str(chain), LPAMD_SHARD_LINK="1", LPAMD_LINK_FAULT="5", LPAMD_LINK_TIMEOUT_MS="300")
+    port = free_port()
+    outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "link_two_process_worker.py"), str(r), str(world), str(port), outs[r],
+                               str(m), str(n), str(seed), ",".join(str(k) for k in legs)], env=env) for r in range(world)]
+    try:
+        codes = [p.wait(timeout=240) for p in procs]
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert codes == [0] * world
+    seen = [json.load(open(f)) for f in outs]
+    dt = lo.DenseTableau.synthetic(m, n, seed)
+    dt.s.skip_zero_cols = 1
+    dt.s.fast_basis = 1
+    assert dt.solve(lo.MAX_COST, max_pivots=sum(legs)) == lo.LIMIT
+    want = [list(t) for t in dt.trace()]
+    for s in seen:
+        assert s["link"] is True
+        assert "error" in s or s["legs"][-1][0] == lpamd.ERROR, "the run went on although a slot never arrived: %r" % (s["legs"],)
+        again = s["again"]
+        assert again["link"] is False and "error" not in again
+        assert again["legs"] == [[lpamd.LIMIT, k] for k in legs]
+        assert again["trace"] == want
