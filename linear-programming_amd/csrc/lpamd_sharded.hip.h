@@ -111,6 +111,38 @@ __global__ __launch_bounds__(256) void k_sum_words(const uint64_t* __restrict__ 
   out[i] = s;
 }
 
+// All-gather of up to `cap` 64-bit words per rank over the ranks' receive buffers, in ONE launch: thread i stores word i of
+// this rank's block into every rank's gather area as a pair of tagged words, then polls word i of every rank's block in its
+// own area (see ShardLink for the tags; `at` = start of the gather area, three sets of `world` blocks of 2 * cap tagged words
+// that take turns).  What a latency-bound collective of a few hundred KiB costs over xGMI is then one store and one poll.
+__global__ __launch_bounds__(256) void k_link_all_gather(
+    const uint64_t* __restrict__ send, uint64_t* __restrict__ recv, int64_t words, int world, int my_rank, uint64_t* const* __restrict__ peers,
+    const uint64_t* __restrict__ in, int64_t at, int64_t cap, uint32_t tag, long long timeout, PivotState* __restrict__ st) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= words) return;
+  const int64_t set = at + (int64_t)(tag % kLinkBuffers) * world * 2 * cap;
+  const uint64_t v = send[i];
+  for (int p = 0; p < world; p++) ll_put(peers[p] + set + ((int64_t)my_rank * cap + i) * 2, v, tag);
+  bool late = false;
+  for (int k0 = 0; k0 < world; k0 += 4) {      // four ranks' words per round trip
+    uint64_t w[4] = {0, 0, 0, 0};
+    const uint64_t* p[4];
+    uint32_t want = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + q < world ? k0 + q : k0;
+      p[q] = in + set + ((int64_t)k * cap + i) * 2;
+      if (k0 + q < world) want |= 1u << q;
+    }
+    const uint64_t* const pc[4] = {p[0], p[1], p[2], p[3]};
+    late |= !ll_get_many<4>(pc, tag, w, want, timeout ? timeout : kLinkTimeoutTicks);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (k0 + q < world) recv[(int64_t)(k0 + q) * words + i] = w[q];
+  }
+  if (late) st->status = ST_ERROR;
+}
+
 // Self-test of the in-launch exchange (ShardLink) when a group is formed: every rank stores a tagged token into every
 // rank's hello words, then looks for every rank's token in its own.
 __global__ __launch_bounds__(kWave) void k_link_hello_put(uint64_t* const* __restrict__ peers, int world, int64_t hello_at, int my_rank) {
@@ -235,6 +267,7 @@ struct lpamd_shard {   // one column shard of a group and its exchange state
   std::vector<void*> link_mapped;            // peers' buffers opened through IPC handles
   uint32_t link_tag = 0;                     // tag of the last slot exported that way
   int64_t link_exports = 0;                  // slots exported that way so far
+  uint32_t gather_tag = 0;                   // tag of the last all-gather that went over the receive buffers
   int rc = LPAMD_OK;
   std::string err;
 };
@@ -250,6 +283,8 @@ struct lpamd_group {
   void* host_ctx = nullptr;
   bool link = false;              // MAX_COST steps of a chain: the slots travel inside the launches, no collective
   int64_t ll_words = 0;           // tagged words per slot
+  bool link_gather = false;       // all-gathers of up to gather_cap words go over the receive buffers too (k_link_all_gather)
+  int64_t gather_cap = 0;
   long long link_timeout = 0;     // ticks a reader waits for a word (0: the kernels' default of ten seconds; LPAMD_LINK_TIMEOUT_MS)
   int64_t link_fault_at = 0;      // experiments only (LPAMD_LINK_FAULT=n): rank 0 mis-tags its n-th slot, which the other ranks then never see
   int chain = 1;                  // pivots per pass of the look-ahead loop
@@ -322,7 +357,15 @@ void abort_comms(Group* g) {
 }
 
 // All-gather of `words` 64-bit words per rank on `stream` (send and recv are device memory).
+int64_t link_gather_at(const Group* g);
+
 int all_gather_words(Group* g, Shard& s, const uint64_t* send, uint64_t* recv, int64_t words, hipStream_t stream) {
+  if (g->link_gather && words <= g->gather_cap) {   // over the ranks' receive buffers: one launch, no collective
+    s.gather_tag = s.gather_tag + 1 == 0 ? 1 : s.gather_tag + 1;
+    hipLaunchKernelGGL(k_link_all_gather, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, send, recv, words, g->world, s.rank,
+                       s.link_peers, s.link_buf, link_gather_at(g), g->gather_cap, s.gather_tag, g->link_timeout, s.eng->st);
+    return check_launch("k_link_all_gather");
+  }
   if (g->host_gather) {   // the caller's collective, staged through host memory; synchronous
     std::vector<uint64_t> mine((size_t)words), every((size_t)words * g->world);
     HIP_TRY(hipMemcpyAsync(mine.data(), send, sizeof(uint64_t) * words, hipMemcpyDeviceToHost, stream));
@@ -844,7 +887,8 @@ void destroy_shard(Group* g, Shard& s) {
   (void)g;
 }
 
-int64_t link_hello_at(const Group* g) { return (int64_t)kLinkBuffers * g->world * g->ll_words; }
+int64_t link_gather_at(const Group* g) { return (int64_t)kLinkBuffers * g->world * g->ll_words; }
+int64_t link_hello_at(const Group* g) { return link_gather_at(g) + (int64_t)kLinkBuffers * g->world * 2 * g->gather_cap; }
 int64_t link_words(const Group* g) { return link_hello_at(g) + 2 * (int64_t)g->world + 64; }
 
 int init_shard(Group* g, Shard& s, int rank, int device) {
@@ -909,6 +953,8 @@ int link_connect_local(Group* g) {
     all = all && ok == 1;
   }
   g->link = all;
+  g->link_gather = all && !g->local_exchange;   // (shards that share a GPU keep their event-ordered copies)
+  if (const char* env = getenv("LPAMD_LINK_GATHER")) g->link_gather = g->link_gather && atoi(env) != 0;
   return LPAMD_OK;
 }
 
@@ -968,6 +1014,10 @@ int link_connect_ranks(Group* g, Shard& s) {
   LP_TRY(gather(1));
   for (int k = 0; k < g->world; k++) good = good && every[k] == 1;
   g->link = good;
+  // every later all-gather of a slot's size or less goes the same way (pass boundary, MAX_REDUCTION steps, in-order loop,
+  // the ranks' agreement); longer ones (rows and objective of the feasibility phase) stay with the collective
+  g->link_gather = good;
+  if (const char* env = getenv("LPAMD_LINK_GATHER")) g->link_gather = g->link_gather && atoi(env) != 0;
   return LPAMD_OK;
 }
 
@@ -999,6 +1049,7 @@ Group* new_group(int64_t m, int64_t N, int world, int32_t flags) {
   // Shards that share a GPU (in-process exchange) order their launches with events on top, see link_fence_local.
   g->ll_words = 2 * (g->slot_words + (g->lda + kPartialThreads - 1) / kPartialThreads);   // + the column's entry at the row of every ratio-test partial
   g->link = g->fused_step && world <= kWave;
+  g->gather_cap = g->slot_words;
   if (const char* env = getenv("LPAMD_SHARD_LINK")) g->link = g->link && atoi(env) != 0;
   if (const char* env = getenv("LPAMD_LINK_TIMEOUT_MS")) g->link_timeout = std::max(1, atoi(env)) * 100000LL;
   if (const char* env = getenv("LPAMD_LINK_FAULT")) g->link_fault_at = atoll(env);

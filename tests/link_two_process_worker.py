@@ -32,6 +32,9 @@ def main():
                 seen["legs"].append([res, done])
                 if res != lp.LIMIT:
                     break
+            tail = int(os.environ.get("LPAMD_TEST_MR_TAIL", "0"))
+            if tail and all(r == lp.LIMIT for r, _ in seen["legs"]):     # the MAX_REDUCTION loop continues the same LP
+                seen["tail"] = list(g.run_pivots(lp.MAX_REDUCTION, tail))
             seen["trace"] = g.trace()
             seen["rhs"] = [float(v).hex() for v in g.engine(0).read_column(n + m)]
         except Exception as ex:   # the test reads the message

@@ -28,7 +28,7 @@ def free_port():
 @pytest.mark.parametrize("world,chain,link", [(2, 8, 1), (3, 5, 1), (2, 8, 0)])
 def test_ranks_in_processes_of_their_own(lpamd, tmp_path, world, chain, link):
     m, n, seed, legs = 2560, 3072, 7, (23, 1, 40, 0, 9)
-    env = dict(os.environ, LPAMD_SHARD_CHAIN=str(chain), LPAMD_SHARD_LINK=str(link))
+    env = dict(os.environ, LPAMD_SHARD_CHAIN=str(chain), LPAMD_SHARD_LINK=str(link), LPAMD_TEST_MR_TAIL="37")
     port = free_port()
     outs = [str(tmp_path / ("rank%d.json" % r)) for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "link_two_process_worker.py"), str(r), str(world), str(port), outs[r],
@@ -46,10 +46,12 @@ def test_ranks_in_processes_of_their_own(lpamd, tmp_path, world, chain, link):
         assert s["chain"] == chain and s["comm_ranks"] == 0
         assert s["link"] == bool(link)
         assert s["legs"] == [[lpamd.LIMIT, k] for k in legs]
+        assert s["tail"] == [lpamd.LIMIT, 37]      # MAX_REDUCTION steps: their all-gathers go over the receive buffers as well
     dt = lo.DenseTableau.synthetic(m, n, seed)
     dt.s.skip_zero_cols = 1
     dt.s.fast_basis = 1
     assert dt.solve(lo.MAX_COST, max_pivots=sum(legs)) == lo.LIMIT
+    assert dt.solve(lo.MAX_REDUCTION, max_pivots=sum(legs) + 37) == lo.LIMIT
     want = [list(t) for t in dt.trace()]
     for s in seen:
         assert s["trace"] == want, "rank %d walked other pivots" % s["rank"]
