@@ -43,6 +43,11 @@ dbg-clock:
 	@mkdir -p bin_scratch
 	$(HIPCC) $(HIPFLAGS) -DLPAMD_DBG_CLOCK -shared -o bin_scratch/liblpamd_dbgclock.so $(CSRC)/lpamd_engine.hip
 
+# experiments only: two processes on one GPU trade tagged words through IPC-mapped uncached memory (the exchange inside the launches)
+link-probe:
+	@mkdir -p bin_scratch
+	$(HIPCC) -O2 --offload-arch=gfx950 -o bin_scratch/link_pingpong scripts/link_pingpong.hip
+
 # experiments only: the engine with index checks in the kernels (tests/conftest.py reads the counters after every test
 # when LPAMD_LIBRARY points at this build)
 dbg-checks:
@@ -52,4 +57,4 @@ dbg-checks:
 clean:
 	rm -rf $(LIBDIR) $(BINDIR) build
 	$(MAKE) -C oracle clean
-.PHONY: all engine host host-bins oracle clean dbg-clock dbg-checks
+.PHONY: all engine host host-bins oracle clean dbg-clock dbg-checks link-probe

@@ -59,6 +59,7 @@ LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_cost --steps 512 --warmup 64
 # the same with the RCCL all-gather in front of every chained step instead of the exchange inside the launches
 LPAMD_SHARD_LINK=0 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --steps 512 --warmup 64 --no-cpu-baseline > $o/shard_of_8_max_cost_collective.json 2>> $o/err.log
 LPAMD_SHARD_LINK=0 LPAMD_BENCH_SHARD_OF=8 stats shard_of_8_max_cost_collective --steps 512 --warmup 64
+LPAMD_SHARD_LINK=0 LPAMD_BENCH_SHARD_OF=8 timeout -k 10 300 python3 -u bench.py --strategy max_reduction --steps 256 --warmup 64 --no-cpu-baseline > $o/shard_of_8_max_reduction_collective.json 2>> $o/err.log
 # two processes on this GPU trading tagged words through IPC-mapped uncached memory while both kernels run
 [ -x bin_scratch/link_pingpong ] && { timeout -k 10 60 ./bin_scratch/link_pingpong 2000 4096; timeout -k 10 60 ./bin_scratch/link_pingpong 2000 64; } > $o/link_pingpong_two_processes.txt 2>> $o/err.log
 # depth of the chain against the pass kernel (k_update_deep from 17 steps on; 16 and below: k_update_slab)
