@@ -202,30 +202,29 @@ def main():
         depth = eng.loop_depth(strat)
         exchange = "none (device-resident loop)"
     else:
-        if use_dist:
+        def form_group():
+            """The group of this run: joined over RCCL (one process per GPU), or a rehearsal on this GPU alone."""
+            if not use_dist:
+                if shard_of > 1:
+                    return lp.ShardGroup(m, N, shard_of, devices=[local_rank] * shard_of, rehearse_rank0=True)
+                return lp.ShardGroup(m, N, 1, devices=[local_rank])
             import threading
+            ids = [lp.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            watchdog = threading.Timer(JOIN_TIMEOUT_S, fail, ["rank %d did not get through ncclCommInitRank within %d s (another rank "
+                                                              "may have failed before it, or RCCL cannot reach its peers)" % (rank, JOIN_TIMEOUT_S)])
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                grp = lp.ShardGroup.join(m, N, rank, world, ids[0])
+            except Exception as ex:
+                fail("rank %d could not create its shard or join the communicator: %s" % (rank, ex))
+            watchdog.cancel()
+            if grp.comm_ranks() != world:
+                fail("the communicator holds %d ranks, WORLD_SIZE is %d" % (grp.comm_ranks(), world))
+            return grp
 
-            def join():
-                ids = [lp.comm_unique_id() if rank == 0 else None]
-                dist.broadcast_object_list(ids, src=0)
-                watchdog = threading.Timer(JOIN_TIMEOUT_S, fail, ["rank %d did not get through ncclCommInitRank within %d s (another rank "
-                                                                  "may have failed before it, or RCCL cannot reach its peers)" % (rank, JOIN_TIMEOUT_S)])
-                watchdog.daemon = True
-                watchdog.start()
-                try:
-                    grp = lp.ShardGroup.join(m, N, rank, world, ids[0])
-                except Exception as ex:
-                    fail("rank %d could not create its shard or join the communicator: %s" % (rank, ex))
-                watchdog.cancel()
-                if grp.comm_ranks() != world:
-                    fail("the communicator holds %d ranks, WORLD_SIZE is %d" % (grp.comm_ranks(), world))
-                return grp
-
-            group = join()
-        elif shard_of > 1:
-            group = lp.ShardGroup(m, N, shard_of, devices=[local_rank] * shard_of, rehearse_rank0=True)
-        else:
-            group = lp.ShardGroup(m, N, 1, devices=[local_rank])
+        group = form_group()
         rccl_ranks = group.comm_ranks()
         group.fill_synthetic(n, args.seed)
         eng = group.engine(0)
@@ -241,8 +240,8 @@ def main():
     if not args.exact_steps:
         K, W = max(round_up(max(K, 1), depth), MIN_TIMED_PASSES * depth), round_up(W, depth)
     link_fallback = None
-    if use_dist and link:
-        # The exchange inside the launches has a self-test behind it but no run on this machine yet: a few passes decide.  If any
+    if link:
+        # The exchange inside the launches has a self-test behind it but no run on this machine yet: two passes decide.  If any
         # rank's do not come through, every rank forms a new group that keeps the collective for every step, and says so.
         try:
             res, done = run(2 * depth)
@@ -250,14 +249,17 @@ def main():
             why = "result %d after %d pivots" % (res, done)
         except Exception as ex:
             good, why = False, str(ex)
-        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        everybody = good
+        if use_dist:
+            flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            everybody = int(flag.item()) == 1
+        if not everybody:
             link_fallback = "the exchange inside the launches failed its trial passes on some rank (rank %d: %s): RCCL all-gather per pivot instead" % (
                 rank, why if not good else "fine here")
             group.close()
             os.environ["LPAMD_SHARD_LINK"] = "0"
-            group = join()
+            group = form_group()
             group.fill_synthetic(n, args.seed)
             eng = group.engine(0)
             link = group.link_active()
