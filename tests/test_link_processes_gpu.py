@@ -59,10 +59,11 @@ def test_ranks_in_processes_of_their_own(lpamd, tmp_path, world, chain, link):
     assert seen[0]["rhs"] == [float(v).hex() for v in dt.T[:, dt.N]], "the right-hand side differs from the oracle's"
 
 
-def test_full_size_ranks_in_processes_of_their_own(lpamd, tmp_path):
-    """m=32768 n=65536 dealt over two processes (12.9 GB each, default depth of 26 pivots per pass, 128 row and 193 column
-    workgroups per launch): the ranks' pivots and right-hand side against the single-engine loop on the same GPU."""
-    m, n, seed, legs, world = 32768, 65536, 1, (61, 30), 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_full_size_ranks_in_processes_of_their_own(lpamd, tmp_path, world):
+    """m=32768 n=65536 dealt over two / four processes (12.9 / 6.4 GB each, default depth of 26 pivots per pass, 128 row and
+    193 / 97 column workgroups per launch): the ranks' pivots and right-hand side against the single-engine loop on the same GPU."""
+    m, n, seed, legs = 32768, 65536, 1, (61, 30)
     env = dict(os.environ, LPAMD_SHARD_LINK="1")
     env.pop("LPAMD_SHARD_CHAIN", None)
     port = free_port()
