@@ -123,6 +123,12 @@ __global__ __launch_bounds__(256) void k_link_all_gather(
   const int64_t set = at + (int64_t)(tag % kLinkBuffers) * world * 2 * cap;
   const uint64_t v = send[i];
   for (int p = 0; p < world; p++) ll_put(peers[p] + set + ((int64_t)my_rank * cap + i) * 2, v, tag);
+  // a rank whose run has failed (a word that never came) gives the others its words and waits for nobody any more: the
+  // launches its host has already enqueued drain at once instead of one time limit each
+  if (st->status == ST_ERROR) {
+    for (int k = 0; k < world; k++) recv[(int64_t)k * words + i] = k == my_rank ? v : 0;
+    return;
+  }
   bool late = false;
   for (int k0 = 0; k0 < world; k0 += 4) {      // four ranks' words per round trip
     uint64_t w[4] = {0, 0, 0, 0};
@@ -505,7 +511,7 @@ uint32_t link_tag_out(Group* g, Shard& s) {
 // ranks would then leave the loop at different reads of the state, one of them with collectives enqueued that the other
 // never joins.  So the ranks of a communicator trade what they have read and all stop as soon as one has stopped.
 int agree_on_result(Group* g, Shard& s, int32_t* res) {
-  if (!g->link || g->local_exchange) return LPAMD_OK;   // (a world of one trades with itself: the rehearsal walks this code)
+  if ((!g->link && !g->link_gather) || g->local_exchange) return LPAMD_OK;   // (a world of one trades with itself: the rehearsal walks this code)
   hipStream_t st = s.eng->stream;
   const uint64_t mine = (uint64_t)(uint32_t)*res;
   std::vector<uint64_t> every(g->world, 0);
@@ -624,6 +630,7 @@ int run_in_order(Group* g, Shard& s, int32_t strategy, int64_t k, int32_t* resul
     }
     enqueued += n;
     LP_TRY(lpamd_poll(e, &res));
+    LP_TRY(agree_on_result(g, s, &res));
     if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
   }
   int64_t now = 0;
@@ -677,6 +684,7 @@ int run_reduction_chain(Group* g, Shard& s, int64_t k, int32_t* result, int64_t*
     }
     enqueued += passes * g->chain_mr;
     LP_TRY(lpamd_poll(e, &res));
+    LP_TRY(agree_on_result(g, s, &res));
     if (res != LPAMD_LIMIT || (k >= 0 && enqueued >= k)) break;
   }
   int64_t now = 0;
