@@ -624,6 +624,8 @@ bool launch_update_slab(lpamd_engine* e) {
   if (e->chain_depth <= 8) return launch_slab_shape<8>(e);
   if (e->chain_depth <= 12) return launch_slab_shape<12>(e);
   if (e->chain_depth <= 16) return launch_slab_shape<16>(e);
+  if (e->chain_depth <= 20) return launch_slab_shape<20>(e);
+  if (e->chain_depth <= 24) return launch_slab_shape<24>(e);   // (32 steps in registers measured slower than 24 at m=4096 n=8192)
   return false;   // longer chains do not fit the registers: k_update_deep, or k_update_chain with col' from L2
 }
 
@@ -1172,7 +1174,11 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // Column shards of that size chain 26: their steps carry the export and the exchange on top of the set-up (20 us per step
   // beside 34 us of pass per pivot on a shard of 8), so the depth that pays is greater than on one GPU (rank 0 of 8: 18.7 k
   // pivots/s at 22, 19.7 k at 26, 19.8 k at 28 and 32; of 2: 6.35 k, 6.78 k, 6.95 k), at 0.67 of the HBM peak per rank.
-  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? (world > 1 ? 26 : 22) : 16);
+  // One GPU, shard inside the Infinity Cache: 24 steps with col' in registers (m=4096 n=8192: 59.5 k pivots/s against 57.9 k at
+  // 16; the pass costs 7.0 us per pivot instead of 7.6 and its fixed costs spread over more pivots); MAX_REDUCTION keeps 16
+  // there (20.6 k at 24 against 21.4 k: its steps grow dearer with their position in the pass).
+  const bool cache_sized_one_gpu = world == 1 && !hbm_sized;
+  e->chain_depth = e->two_launch ? 1 : (hbm_sized ? (world > 1 ? 26 : 22) : (cache_sized_one_gpu ? 24 : 16));
   // One GPU, HBM-sized shard: the depth is MEASURED on this device once everything is allocated (probe_chain_depth), from
   // kProbeMaxDepth down; the buffers are sized for that.  Column shards keep their constant: every rank must chain the same number of steps.
   bool probe_depth = world == 1 && hbm_sized && !e->two_launch;
@@ -1192,6 +1198,7 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   // n=65536: 10.9 k against 10.0 k pivots/s), on a 21 GB shard slower (rank 0 of 8 of m=65536 n=262144: 2.70 k against 2.95 k)
   if (world > 1 && hbm_sized && !getenv("LPAMD_CHAIN") && deal_bytes < 8e9)
     e->mr_depth = std::min(e->chain_depth, 22);
+  if (cache_sized_one_gpu && !getenv("LPAMD_CHAIN")) e->mr_depth = std::min(e->chain_depth, 16);
   if (const char* env = getenv("LPAMD_MR_CHAIN")) { if (e->chain_depth > 1) e->mr_depth = std::max(2, std::min(kMaxChain, atoi(env))); }
   e->alloc_depth = std::max(e->chain_depth, e->mr_depth);
   // Measured (m=32768 n=65536): col' from L2 8.44 ms per pass of 8 pivots; in registers, 1024-row slabs x 8 columns in
@@ -1200,7 +1207,9 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
   e->slab_shape = (e->sh.lda % 1024 == 0 && hbm_sized) ? 4 : 1;
   if (const char* env = getenv("LPAMD_SLAB")) e->slab_shape = atoi(env);
   if (const char* env = getenv("LPAMD_SLAB_GRID")) e->slab_grid = std::max(1, atoi(env));
-  e->deep_batch = (e->alloc_depth > 16 && e->sh.lda % (2 * kWave) == 0) ? 8 : 0;
+  // col' in LDS (k_update_deep) for chains beyond 16 steps on HBM-sized shards; inside the Infinity Cache the register kernel
+  // serves up to 24 steps and is twice as fast there (0.167 against 0.278 ms per pass of 24 at m=4096 n=8192)
+  e->deep_batch = (e->alloc_depth > (hbm_sized ? 16 : 24) && e->sh.lda % (2 * kWave) == 0) ? 8 : 0;
   if (const char* env = getenv("LPAMD_DEEP")) { e->deep_batch = (e->chain_depth > 1 && e->sh.lda % (2 * kWave) == 0) ? atoi(env) : 0; e->deep_any_depth = true; }
   if (e->deep_batch != 4 && e->deep_batch != 8) e->deep_batch = 0;
   if (const char* env = getenv("LPAMD_DEEP_GRID")) e->deep_grid = std::max(0, atoi(env));
