@@ -94,3 +94,23 @@ def test_create_rejects_shapes_beyond_31_bits():
         rc = L.lpamd_create(ctypes.byref(h), m, N, 0, world, None)
         assert rc != 0 and not h.value
         assert b"31 bits" in L.lpamd_last_error()
+
+
+def test_group_creation_checks_its_arguments_before_any_device_or_collective():
+    """A rank with bad arguments must fail BEFORE it enters a collective (the others would wait for it):
+    both per-rank forms check the world, the rank and their collective first."""
+    lp = lpamd_pkg()
+    L = lp.library()
+    h = ctypes.c_void_p()
+    ident = ctypes.create_string_buffer(128)
+    gather = lp.engine.HOST_ALLGATHER(lambda ctx, send, recv, nbytes: 0)
+    cb = ctypes.cast(gather, ctypes.c_void_p)
+    for m, N, rank, world in ((4, 8, 0, 0), (4, 8, 2, 2), (4, 8, -1, 2), (4, 8, 0, 10), (0, 8, 0, 1)):
+        assert L.lpamd_group_create_rank(ctypes.byref(h), m, N, rank, world, ident) != 0 and not h.value
+        assert b"bad arguments" in L.lpamd_last_error()
+        assert L.lpamd_group_create_rank_hosted(ctypes.byref(h), m, N, rank, world, cb, None) != 0 and not h.value
+        assert b"bad arguments" in L.lpamd_last_error()
+    assert L.lpamd_group_create_rank(ctypes.byref(h), 4, 8, 0, 1, None) != 0 and b"no communicator id" in L.lpamd_last_error()
+    assert L.lpamd_group_create_rank_hosted(ctypes.byref(h), 4, 8, 0, 1, None, None) != 0 and b"no all-gather function" in L.lpamd_last_error()
+    active = ctypes.c_int32(7)
+    assert L.lpamd_group_link_active(None, ctypes.byref(active)) != 0
