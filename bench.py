@@ -8,8 +8,8 @@ resident in HBM before the timed region starts.
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--strategy max_cost|max_reduction]
 
 N == 1 runs the device-resident loop of the C ABI (lpamd_run_pivots).  N > 1 runs the
-column-sharded loop of the library (lpamd_group_*: one RCCL all-gather per pivot, chains of
-pivots per pass over the shard), one process per GPU: either the driver starts the ranks with
+column-sharded loop of the library (lpamd_group_*: chains of pivots per pass over the shard; the
+ranks trade their candidates inside the launches over xGMI, or with one RCCL all-gather per pivot), one process per GPU: either the driver starts the ranks with
 torch.distributed.run, or a plain `python bench.py --gpus N` starts them itself (as a child
 torch.distributed.run, before this process touches a GPU).  Rank 0 prints ONE JSON line.
 
@@ -232,8 +232,8 @@ def main():
         depth = min(group.chain(), eng.loop_depth(strat))   # MAX_REDUCTION passes may be shorter than MAX_COST ones
         link = group.link_active()
         exchange = ("inside a pass every rank stores its slot (record + candidate column + its ratio-test partials, tagged words) into the "
-                    "peers' receive buffers from inside the step's own launch, no collective; at the pass boundary one RCCL all-gather "
-                    "beside the pass kernel" if link else
+                    "peers' receive buffers from inside the step's own launch, no collective; at the pass boundary one all-gather over "
+                    "the same buffers (one launch) beside the pass kernel" if link else
                     "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library")
 
     K, W = args.steps, args.warmup
