@@ -196,6 +196,28 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
       first_b[q] = __hip_atomic_load(rec_at + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  // kIn, column workgroups (they are the ones everybody waits for): the ratio-test partials of EVERY rank go out with that
+  // first look, up to four triples per thread, so that once the winner is known its partials are already here and the pivot
+  // needs no second round trip to uncached memory (2 us each).  The row workgroups, which wait for the column workgroups'
+  // pricing anyway, read only the winner's.
+  const int n_spec = (int)blockIdx.x >= n_row_blocks ? slot_world * n_ratio_part : 0;
+  const bool spec = kIn && n_spec > 0 && n_spec <= 4 * kThreads;
+  uint64_t sp_a[4][3], sp_b[4][3];
+  if (spec) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = tid + q * kThreads;
+      if (t < n_spec) {
+        const int k = t / n_ratio_part, x = t - k * n_ratio_part;
+        const uint64_t* part = link.in + ((int64_t)(link.tag_in % kLinkBuffers) * slot_world + k) * link.ll_words + 2 * ((int64_t)slot_header + sh.lda);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          sp_a[q][c] = __hip_atomic_load(part + 2 * ((int64_t)c * n_ratio_part + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          sp_b[q][c] = __hip_atomic_load(part + 2 * ((int64_t)c * n_ratio_part + x) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
   int32_t q_in = -1, q_out = -1;
   int64_t q_e = -1, q_r = -1;
   if (lane == 0) { q_in = st->l_e; q_out = st->l_d; q_e = st->e; q_r = st->r; }
@@ -269,7 +291,35 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_shard_step(
   int64_t r2 = -1;
   double my_a = 0.0;      // kIn: the winner's column at the row of this thread's best partial
   int64_t my_r = -1;
-  if (kIn) {
+  if (spec) {
+    // the winner's triples among those this thread asked for on entry; one that had not arrived then is polled now
+    const uint64_t* part = ll_mine + 2 * ((int64_t)slot_header + sh.lda);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int t = tid + q * kThreads;
+      const int k = t < n_spec ? t / n_ratio_part : -1;
+      if (k == w) {
+        const int x = t - k * n_ratio_part;
+        uint64_t w3[3] = {0, ~0ull, 0};
+        uint32_t missing = 0;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+          if ((uint32_t)sp_a[q][c] == link.tag_in && (uint32_t)sp_b[q][c] == link.tag_in) w3[c] = (sp_a[q][c] >> 32) | (sp_b[q][c] & 0xFFFFFFFF00000000ull);
+          else missing |= 1u << c;
+        }
+        if (missing) {
+          const uint64_t* const p3[3] = {part + 2 * (int64_t)x, part + 2 * ((int64_t)n_ratio_part + x), part + 2 * (2 * (int64_t)n_ratio_part + x)};
+          late |= !ll_get_many<3>(p3, link.tag_in, w3, missing, link.timeout ? link.timeout : kLinkTimeoutTicks);
+        }
+        if (!late) {
+          const int64_t before = r2;
+          take_min(best, r2, __longlong_as_double((long long)w3[0]), (int64_t)w3[1]);
+          if (r2 != before) my_a = __longlong_as_double((long long)w3[2]);
+        }
+      }
+    }
+    my_r = r2;
+  } else if (kIn) {
     // this thread's row of the column and its first triple of ratio-test partials (ratio, row, the column's entry at that
     // row) in one round trip; the entry travels with the partial so that the pivot element needs no read of its own
     const uint64_t* part = ll_mine + 2 * ((int64_t)slot_header + sh.lda);
