@@ -712,7 +712,8 @@ int enqueue_prb_pricing(lpamd_engine* e, int j, Candidate* cand, bool record_ste
 }
 
 // Step j >= 1 of a pass on one GPU: rows, bounds, then exact evaluation, fold and set-up in one launch (k_prb_tail).
-int enqueue_prb_step_tail(lpamd_engine* e, int j) {
+// slot_cand / slot_col (column shards): the launch ends with this rank's candidate packed for the exchange instead of the set-up.
+int enqueue_prb_step_tail(lpamd_engine* e, int j, Candidate* slot_cand = nullptr, double* slot_col = nullptr) {
   int n_bound_blocks = 0;
   LP_TRY(enqueue_prb_bounds(e, j, true, &n_bound_blocks));
   const size_t words = (size_t)kFusedReplicas * (fused_region_words(e->tail_rows + e->tail_cols, kTailEvalWords) + fused_region_words(e->tail_rows + e->tail_cols, kTailBackWords));
@@ -722,15 +723,17 @@ int enqueue_prb_step_tail(lpamd_engine* e, int j) {
     e->tail_epoch = 1;
   }
   const int grid = e->tail_rows + e->tail_cols;
-#define LPAMD_LAUNCH_TAIL(REC)                                                                                                          \
-  hipLaunchKernelGGL(k_prb_tail<REC>, dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->tail_rows, e->colp, \
+#define LPAMD_LAUNCH_TAIL_AS(REC, SHARD)                                                                                                 \
+  hipLaunchKernelGGL((k_prb_tail<REC, SHARD>), dim3(grid), dim3(kPartialThreads), 0, e->stream, e->T, e->sh, e->st, e->steps, j, e->tail_rows, e->colp, \
                      e->rowp, e->rstride, e->rhs_next, e->obj, e->is_basic, e->basis, e->trace, e->trace_cap, e->prb_top_u, e->prb_top_l,   \
                      e->prb_top_u + kMaxPartials, n_bound_blocks, e->prb_ub, e->prb_ucand, e->prb_info, e->rec_tail,                     \
-                     e->rec_tail + (size_t)kFusedReplicas * fused_region_words(grid, kTailEvalWords), e->tail_epoch)
+                     e->rec_tail + (size_t)kFusedReplicas * fused_region_words(grid, kTailEvalWords), e->tail_epoch, slot_cand, slot_col)
+#define LPAMD_LAUNCH_TAIL(REC) do { if (slot_cand) LPAMD_LAUNCH_TAIL_AS(REC, true); else LPAMD_LAUNCH_TAIL_AS(REC, false); } while (0)
   if (n_bound_blocks <= kPartialThreads) LPAMD_LAUNCH_TAIL(1);
   else if (n_bound_blocks <= 2 * kPartialThreads) LPAMD_LAUNCH_TAIL(2);
   else if (n_bound_blocks <= 4 * kPartialThreads) LPAMD_LAUNCH_TAIL(4);
   else LPAMD_LAUNCH_TAIL(8);
+#undef LPAMD_LAUNCH_TAIL_AS
 #undef LPAMD_LAUNCH_TAIL
   return check_launch("k_prb_tail");
 }
@@ -759,6 +762,8 @@ int enqueue_prb_pass(lpamd_engine* e) {
 int prb_shard_price(lpamd_engine* e, uint64_t* slot, int header_words) {
   const int j = e->update_pending ? e->pending_steps : 0;
   Candidate* rec = reinterpret_cast<Candidate*>(slot);
+  // steps 1.. of a pass: everything behind the bounds, the record and the column in one launch (k_prb_tail<.., shard>)
+  if (e->prb_tail && j >= 1) return enqueue_prb_step_tail(e, j, rec, reinterpret_cast<double*>(slot + header_words));
   LP_TRY(enqueue_prb_pricing(e, j, rec, false));
   hipLaunchKernelGGL(k_prb_export, dim3((unsigned)((e->sh.lda + kPartialThreads - 1) / kPartialThreads)), dim3(kPartialThreads), 0, e->stream, e->T,
                      e->sh, e->st, e->steps, j, e->colp, e->rowp, e->rstride, rec, reinterpret_cast<double*>(slot + header_words));
@@ -1271,11 +1276,11 @@ static int create_impl(lpamd_engine* e, int64_t m, int64_t N, int64_t nloc, int3
     LP_TRY(dev_alloc(e, (void**)&e->prb_erow, sizeof(int64_t) * e->ncl, "prb_erow"));
     // k_prb_tail: every workgroup of its grid must be resident at the same time (they wait for each other's records); the
     // grid may take three quarters of what the device holds of the kernel, and 512 workgroups at most (record polls)
-    e->prb_tail = world == 1;
+    e->prb_tail = true;   // (column shards: the launch ends with the candidate packed for the exchange)
     if (const char* env = getenv("LPAMD_PRB_TAIL")) e->prb_tail = e->prb_tail && atoi(env) != 0;
     if (e->prb_tail) {
       int per_cu = 0, cus = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_prb_tail<8>, kPartialThreads, 0) != hipSuccess ||
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_prb_tail<8, false>, kPartialThreads, 0) != hipSuccess ||
           hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
       const int64_t room = std::min<int64_t>(kTailMaxGroups, (int64_t)per_cu * cus * 3 / 4);
       e->tail_rows = (int32_t)std::min<int64_t>(128, std::max<int64_t>(1, (m + kPartialThreads - 1) / kPartialThreads));

@@ -43,7 +43,11 @@ struct TailPick {          // the pivot a fold names
 };
 
 // kRec: records of k_prb_bounds per thread (n_top <= kRec * 256)
-template <int kRec>
+// kShard: column shards.  The pivot the fold names is this rank's CANDIDATE, not yet the step's pivot: instead of the set-up
+// (4.) the launch packs it for the exchange, the record into slot_cand and the column, rebuilt through the steps so far,
+// into slot_col (what k_prb_pick and k_prb_export do after k_prb_first / list / eval: five launches in one); "no candidate"
+// travels as gcol = -1, and the set-up follows the exchange (k_chain_finalize from the slots).
+template <int kRec, bool kShard>
 __global__ __launch_bounds__(kPartialThreads, 2) void k_prb_tail(
     Tab T, Shape sh, PivotState* __restrict__ st, ChainStep* __restrict__ steps, int j, int n_rb,
     double* __restrict__ colp, double* __restrict__ rowp, int64_t rstride, double* __restrict__ rhsv,
@@ -51,7 +55,8 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_prb_tail(
     int64_t* __restrict__ trace, int64_t trace_cap,
     const double* __restrict__ top_u1, const int32_t* __restrict__ top_l1, const double* __restrict__ top_u2, int n_top,
     const double* __restrict__ ub, const uint8_t* __restrict__ ucand, PrbInfo* __restrict__ info,
-    uint64_t* __restrict__ rec_eval, uint64_t* __restrict__ rec_back, uint32_t epoch) {
+    uint64_t* __restrict__ rec_eval, uint64_t* __restrict__ rec_back, uint32_t epoch,
+    Candidate* __restrict__ slot_cand, double* __restrict__ slot_col) {
   constexpr int kThreads = kPartialThreads;
   constexpr int kWaves = kThreads / kWave;
   static_assert(kWaves == kTailCols, "one wavefront per column evaluated up front");
@@ -97,7 +102,10 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_prb_tail(
     ru2[q] = in ? top_u2[k] : -DBL_MAX;
     keys[q] = rl[q] >= 0 ? arg_key<true>(u1, 0) : 0;
   }
-  if (!prb_step_alive(st, steps, j)) return;
+  auto no_candidate = [&]() {              // kShard: what the other ranks read when this one has nothing to offer
+    if (kShard && blockIdx.x == 0 && threadIdx.x == 0) { Candidate c; c.key = -DBL_MAX; c.gcol = -1; c.row = -1; c.ce = 0.0; *slot_cand = c; }
+  };
+  if (!prb_step_alive(st, steps, j)) { no_candidate(); return; }
   const double* __restrict__ rhs = prb_rhs(T, sh, rhsv, j);
 
   LPAMD_CLK(j, 2, 1, w == 0);
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_prb_tail(
   }
   __syncthreads();
   const int n_cols = s_ncols;
-  if (n_cols == 0) return;               // no candidate column: optimal after step j-1
+  if (n_cols == 0) { no_candidate(); return; }   // no candidate column: optimal after step j-1
   double t_rest = s_nvalid > kTailCols ? s_next : -DBL_MAX;    // T: the largest bound among the candidates left out
   for (int c = 0; c < n_cols; c++) t_rest = fmax(t_rest, s_cu2[c]);
   const bool none_left = t_rest == -DBL_MAX;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_prb_tail(
     if (fl >= 0 && (pick.col < 0 || fv > pick.score || (fv == pick.score && fl < pick.col))) { pick.score = fv; pick.col = (int32_t)fl; pick.row = s_row; back_ce = s_ce; from_back = true; }
     n_exact += 1;     // counted as one more evaluation round
   }
-  if (pick.col < 0) return;              // no candidate has an eligible row: unbounded after step j-1
+  if (pick.col < 0) { no_candidate(); return; }   // no candidate has an eligible row: unbounded after step j-1 (the next pass's first pricing reports it)
 
   LPAMD_CLK(j, 2, 5, w == 0);
   LPAMD_CLK(j, 3, 5, w == n_rb);
@@ -283,6 +291,23 @@ __global__ __launch_bounds__(kPartialThreads, 2) void k_prb_tail(
   double ce2 = back_ce;
   if (!from_back)
     for (int c = 0; c < n_cols; c++) if (s_col[c] == l_e2) ce2 = s_cobj[c];
+  if (kShard) {
+    // ---- 4'. this rank's candidate, packed for the exchange
+    if (w == 0 && tid == 0) {
+      Candidate c;
+      c.key = pick.score; c.gcol = e2; c.row = r2; c.ce = ce2;
+      *slot_cand = c;
+      info->priced += 1;
+      info->listed += n_exact - 1;
+    }
+    if (row_block) {
+      const int64_t stride = (int64_t)n_rb * kThreads;
+      for (int64_t i = (int64_t)w * kThreads + tid; i < sh.lda; i += stride)
+        slot_col[i] = i < sh.m ? chain_apply(ecol[i], j, colp + i, sh.lda, rowp + l_e2, rstride) : 0.0;
+    }
+    (void)cb; (void)n_cb; (void)rhs_prev; (void)it;
+    return;
+  }
   const double a2 = chain_apply(ecol[r2], j, colp + r2, sh.lda, rowp + l_e2, rstride);
   const double f2 = -1.0 / a2;
   const double g2 = __dmul_rn(ce2, f2);
