@@ -245,12 +245,14 @@ int lpamd_poll(lpamd_engine* eng, int32_t* result);
  * multi-GPU steps above), driven through TableauSimplexSolve (reference
  * lp_simplex_tableau.cc:173-379) by the library itself.  The reference has no counterpart: its only
  * parallelism is OpenMP inside List::Map (reference lp_simplex_tableau.cc:253-309).  Per pivot the
- * shards trade ONE RCCL all-gather: every rank sends its best local candidate, record and column
+ * shards trade ONE exchange: every rank sends its best local candidate, record and column
  * and (MAX_COST) the ratio-test partials it took on that column (world * (64 + 8.06 * lda) bytes
  * arrive per rank), every rank folds the records with the reference's tie-break (largest key,
  * lowest column) and takes the winner's column; both strategies set up several pivots per pass
  * over the shard (lpamd_group_chain), the exchange of the pass after travels on a second stream
- * beside the rank-1 update.  Results equal the single-engine loop bit for bit.
+ * beside the rank-1 update.  The exchange is an RCCL all-gather, or, where the ranks can map each
+ * other's memory, stores into the peers' receive buffers from inside the launches
+ * (lpamd_group_link_active).  Results equal the single-engine loop bit for bit.
  *
  * lpamd_group_create: ONE process drives n_shards GPUs (devices[k] for shard k, NULL = 0..n-1),
  * one host thread and one communicator per shard (ncclCommInitAll).  With
