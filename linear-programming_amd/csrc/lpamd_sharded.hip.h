@@ -21,6 +21,13 @@
 // set-up kernel of every rank folds records and partials itself: two launches and the
 // collective per pivot (fused_step; MAX_REDUCTION records bring their rows instead).
 //
+// Where the ranks can map each other's memory the collective itself goes (link, ShardLink in
+// lpamd_shardstep_kernels.hip.h): the launch that sets a step up stores this rank's slot for the next
+// step straight into every rank's receive buffer as tagged words, which the next launch polls, and
+// the other all-gathers of a slot's size or less are one launch over the same buffers
+// (k_link_all_gather).  RCCL then forms the group, trades the buffers' handles, carries the long
+// vectors of the feasibility phase, and takes everything back if the self-test of the mapping fails.
+//
 // LPAMD_GROUP_LOCAL_EXCHANGE replaces RCCL by device copies between the shards of one process
 // (events + host barriers).  It exists so that several shards can share ONE GPU, which RCCL
 // refuses, for tests on a one-GPU machine; it also works across GPUs with peer access.
