@@ -264,6 +264,40 @@ def main():
             eng = group.engine(0)
             link = group.link_active()
             exchange = "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library"
+    exchange_trial = None
+    trial_both = os.environ.get("LPAMD_BENCH_TRIAL_BOTH", "1")      # "0": never; "force": also in the one-GPU rehearsals
+    if link and ((use_dist and world > 1 and trial_both != "0") or trial_both == "force"):
+        # Which exchange is faster on THIS node is a measurement, not an assumption (the stores into the peers' buffers have
+        # been timed between processes on one GPU, never over xGMI): three passes of each, a second group beside the first,
+        # the slower one is closed.  Every rank takes the same decision from the slowest rank's times.
+        def timed(grp, k):
+            sync_all()
+            t = time.perf_counter()
+            r, d = grp.run_pivots(strat, k)
+            sync_all()
+            t = time.perf_counter() - t
+            both = torch.tensor([t, 0.0 if (d == k and r == lp.LIMIT) else 1.0], dtype=torch.float64, device=dev)
+            if use_dist:
+                dist.all_reduce(both, op=dist.ReduceOp.MAX)
+            return float(both[0].item()), float(both[1].item()) == 0.0
+        t_link, ok_link = timed(group, 3 * depth)
+        os.environ["LPAMD_SHARD_LINK"] = "0"
+        other = form_group()
+        os.environ["LPAMD_SHARD_LINK"] = "1"
+        other.fill_synthetic(n, args.seed)
+        other.run_pivots(strat, depth)
+        t_coll, ok_coll = timed(other, 3 * depth)
+        exchange_trial = {"pivots": 3 * depth, "inside_the_launches_ms": round(t_link * 1e3, 3), "collective_ms": round(t_coll * 1e3, 3)}
+        if ok_coll and (not ok_link or t_coll < 0.97 * t_link):
+            group.close()
+            group = other
+            eng = group.engine(0)
+            link = group.link_active()
+            exchange = "one RCCL all-gather per pivot (record + candidate column + its ratio-test partials per rank), inside the library"
+            exchange_trial["kept"] = "collective"
+        else:
+            other.close()
+            exchange_trial["kept"] = "inside the launches"
     res, done = run(W)
     assert done == W and res == lp.LIMIT, "warm-up ended early: result %d after %d pivots" % (res, done)
     sync_all()
@@ -329,6 +363,7 @@ def main():
                    "seed": args.seed, "sharding": "columns round-robin over %d GPU(s), RHS replicated" % world,
                    "exchange": exchange, "exchange_in_launch": bool(group is not None and link),
                    **({"exchange_fallback": link_fallback} if link_fallback else {}),
+                   **({"exchange_trial": exchange_trial} if exchange_trial else {}),
                    **({"replicas_walked_the_same_pivots": replicas_agree} if replicas_agree is not None else {}),
                    "pivots_per_pass": depth, "rccl_ranks": rccl_ranks,
                    **({"rehearsal": "rank 0 of a %d-GPU run alone on one GPU" % shard_of} if shard_of > 1 else {})},
