@@ -834,9 +834,12 @@ int enqueue_chain_update(lpamd_engine* e) {
   }
   // which pass kernel: the one with col' in LDS for chains beyond the 16 steps the registers hold (the depth differs by strategy)
   const bool deep = e->deep_batch > 0 && (e->chain_depth > 16 || e->deep_any_depth);
-  hipLaunchKernelGGL(k_chain_list, dim3((unsigned)((e->ncl + kListThreads - 1) / kListThreads)), dim3(kListThreads), 0, e->stream, e->rowp, e->rstride, e->chain_depth, e->steps,
-                     e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, deep ? e->deep_batch : 0, e->T,
-                     e->ptr_full, e->fused_pending ? 1 : 0);
+#define LPAMD_LAUNCH_LIST(THREADS)                                                                                                       \
+  hipLaunchKernelGGL(k_chain_list<THREADS>, dim3((unsigned)((e->ncl + THREADS - 1) / THREADS)), dim3(THREADS), 0, e->stream, e->rowp, e->rstride, \
+                     e->chain_depth, e->steps, e->st, e->ncl, e->pass, e->list_full, e->list_part, e->rsl_full, e->rsl_part, e->chain_depth, \
+                     deep ? e->deep_batch : 0, e->T, e->ptr_full, e->fused_pending ? 1 : 0)
+  if (e->ncl <= 32768) LPAMD_LAUNCH_LIST(256); else LPAMD_LAUNCH_LIST(1024);
+#undef LPAMD_LAUNCH_LIST
   e->fused_pending = false;
   LP_TRY(check_launch("k_chain_list"));
   const int n_slabs = std::min(e->n_slabs, e->update_unroll_cap);

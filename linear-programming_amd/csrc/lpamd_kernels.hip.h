@@ -1260,7 +1260,11 @@ __device__ __forceinline__ int64_t deep_run_index(int k, int s, int depth, int c
 // listed column, zero beyond the chain), which the pass reads as one short run per column.  batch > 0: list_full's
 // runs in the layout of deep_run_index instead, and the address of every column of list_full in ptr_full.
 // bump_iter: the pivot count still lacks steps 1.. of this pass (k_chain_fused) and is advanced here.
-constexpr int kListThreads = 1024;   // one reservation in the lists per workgroup: the counters are single words every workgroup adds to
+// kListThreads: one reservation in the lists per workgroup (the counters are single words every workgroup adds to), so a
+// shard of many columns wants large workgroups (98 k columns: 1024 threads, 96 reservations); a shard of a few thousand
+// columns is a dozen such workgroups, too few to hide the loads, and wants small ones (m=4096 n=8192, 12 k columns: 17.4 us
+// with 1024 threads, 59.5 k pivots/s; 61.0 k with 256).
+template <int kListThreads>
 __global__ __launch_bounds__(kListThreads) void k_chain_list(
     const double* __restrict__ rowp, int64_t rstride, int depth, const ChainStep* __restrict__ steps,
     const PivotState* __restrict__ st, int ncl, PassInfo* __restrict__ pass,
