@@ -273,7 +273,10 @@ def main():
         def timed(grp, k):
             sync_all()
             t = time.perf_counter()
-            r, d = grp.run_pivots(strat, k)
+            try:
+                r, d = grp.run_pivots(strat, k)
+            except Exception:
+                r, d = lp.ERROR, -1
             sync_all()
             t = time.perf_counter() - t
             both = torch.tensor([t, 0.0 if (d == k and r == lp.LIMIT) else 1.0], dtype=torch.float64, device=dev)
@@ -285,7 +288,7 @@ def main():
         other = form_group()
         os.environ["LPAMD_SHARD_LINK"] = "1"
         other.fill_synthetic(n, args.seed)
-        other.run_pivots(strat, depth)
+        timed(other, depth)
         t_coll, ok_coll = timed(other, 3 * depth)
         exchange_trial = {"pivots": 3 * depth, "inside_the_launches_ms": round(t_link * 1e3, 3), "collective_ms": round(t_coll * 1e3, 3)}
         if ok_coll and (not ok_link or t_coll < 0.97 * t_link):
